@@ -1,0 +1,145 @@
+/* xhe.h -- C ABI of the MI355X batch-verification engine for XELIS-HE confidential transactions.
+ *
+ * The reference (xelis-project/xelis-he, a Rust crate) has no FFI layer; the seams this ABI replaces
+ * are the Rust calls named beside each entry point.  Every entry point takes plain pointers and sizes;
+ * all multi-byte integers in buffers are little-endian unless stated; all buffers are caller-owned
+ * host memory unless the name says "_dev".  Return value: 0 = the call ran (the verdict is in the out
+ * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU and one HIP stream and
+ * must not be used from two threads at once; different contexts are independent.
+ */
+#ifndef XHE_H
+#define XHE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xhe_ctx xhe_ctx;
+
+/* call-level errors */
+#define XHE_E_ARG (-1)        /* bad argument (null pointer, size out of range)              */
+#define XHE_E_HIP (-2)        /* HIP runtime error, see xhe_last_error()                     */
+#define XHE_E_NO_DEVICE (-3)  /* no usable gfx950 device                                     */
+#define XHE_E_DECODE (-4)     /* level-0 only: a compressed point of the input does not decode */
+
+/* verdict error codes: the variants of the reference's VerificationError / ProofVerificationError
+ * (src/tx/verify.rs:16-21, src/lib.rs:71-89) plus one for records the reference's serde layer would
+ * already have refused. */
+#define XHE_OK 0
+#define XHE_ERR_STATE 1
+#define XHE_ERR_INVALID_NONCE 2
+#define XHE_ERR_SIGNATURE 3
+#define XHE_ERR_DECOMPRESSION 4
+#define XHE_ERR_COMMITMENT_EQ 5
+#define XHE_ERR_CT_VALIDITY 6
+#define XHE_ERR_GENERIC_PROOF 7
+#define XHE_ERR_RANGE_PROOF 8
+#define XHE_ERR_TRANSCRIPT_IDENTITY 9
+#define XHE_ERR_FORMAT 10
+#define XHE_ERR_MALFORMED 11
+
+/* transaction types (src/tx/mod.rs:85-93) */
+#define XHE_TX_TRANSFERS 0
+#define XHE_TX_BURN 1
+#define XHE_TX_MULTISIG 2
+#define XHE_TX_CALL_CONTRACT 3
+#define XHE_TX_DEPLOY_CONTRACT 4
+
+/* One GPU per context.  device_id is the HIP device ordinal.  Returns NULL on failure
+ * (xhe_last_error(NULL) then describes it). */
+xhe_ctx *xhe_create(int device_id);
+void xhe_destroy(xhe_ctx *ctx);
+const char *xhe_last_error(const xhe_ctx *ctx);
+
+/* ---- level 0: the operator seams --------------------------------------------------------------- */
+
+/* RistrettoPoint::vartime_multiscalar_mul (src/proofs.rs:50-60): out32 = encoding of sum scalars[i] *
+ * points[i]; scalars are 32-byte little-endian integers taken modulo the group order; points are
+ * RFC 9496 encodings.  is_identity receives RistrettoPoint::is_identity() of the sum (src/proofs.rs:62).
+ * n may be 0 (result: identity).  Returns XHE_E_DECODE if a point does not decode. */
+int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, const uint8_t *points32,
+                        uint8_t out32[32], uint8_t *is_identity);
+
+/* CompressedRistretto::decompress over a batch (src/compressed.rs:28-33,57-62,78-83,100-105):
+ * out_xyzt128 receives canonical X,Y,Z,T (4 x 32 bytes) per point, ok[i] = 1 when the encoding is valid
+ * (the output of an invalid one is the identity). */
+int32_t xhe_ristretto_decompress_batch(xhe_ctx *ctx, uint64_t n, const uint8_t *in32, uint8_t *out_xyzt128,
+                                       uint8_t *ok);
+/* RistrettoPoint::compress over a batch (src/compressed.rs:18-20,44-49,72-74,94-96). */
+int32_t xhe_ristretto_compress_batch(xhe_ctx *ctx, uint64_t n, const uint8_t *in_xyzt128, uint8_t *out32);
+
+/* ---- level 1: Transaction::verify_batch (src/tx/verify.rs:487-517) --------------------------------
+ *
+ * Transaction record (the reference has no wire format: Transaction::to_bytes, verify.rs:623-688, is
+ * only a signing pre-image).  One record =
+ *   header, 16 bytes: u8 type, u8 flags (bit0: the multisig field is Some), u16 n_items (Transfers:
+ *     transfers; MultiSig: signers; CallContract: assets; else 0), u16 n_commitments, u16 n_multisig,
+ *     u32 opaque_len (DeployContract: code bytes; CallContract: params bytes; else 0), u16 rp_len
+ *     (range-proof bytes), u16 zero;
+ *   Transfers only: n_items x u32 extra_len (byte length of ExtraData::to_bytes, 0 = None);
+ *   the signing pre-image exactly as Transaction::to_bytes lays it out, without multisig entries:
+ *     version u8, source[32], fee BE u64, nonce BE u64, type payload, range proof, then per commitment
+ *     asset[32], commitment[32], CommitmentEqProof[192];
+ *   n_multisig x (u8 signer index, signature[64]);
+ *   signature[64] = s || e.
+ * A batch is the concatenation of records plus offsets[n+1] (offsets[i] = first byte of record i,
+ * offsets[n] = total length).
+ */
+typedef struct xhe_ledger_view {
+    uint64_t n_accounts;
+    const uint8_t *account_keys;        /* n_accounts x 32: compressed public keys                  */
+    const uint64_t *account_nonces;     /* n_accounts                                               */
+    uint64_t n_balances;
+    const uint32_t *balance_account;    /* n_balances: index into accounts                          */
+    const uint8_t *balance_assets;      /* n_balances x 32                                          */
+    const uint8_t *balance_cts;         /* n_balances x 64: commitment || handle                    */
+    uint64_t n_multisig;
+    const uint32_t *multisig_account;   /* n_multisig: index into accounts                          */
+    const uint8_t *multisig_threshold;  /* n_multisig                                               */
+    const uint32_t *multisig_offsets;   /* n_multisig + 1: ranges into multisig_signers             */
+    const uint8_t *multisig_signers;    /* 32 bytes each                                            */
+} xhe_ledger_view;
+
+typedef struct xhe_ledger_out {
+    uint8_t *balance_cts;      /* n_balances x 64, may alias the input; written only on accept       */
+    uint64_t *account_nonces;  /* n_accounts (the reference stores the nonce back unchanged)         */
+    int64_t *multisig_set_by;  /* n_accounts: index of the last transaction of the batch that set the
+                                  account's multisig configuration (take signers/threshold from that
+                                  record), -1 if none                                                */
+} xhe_ledger_out;
+
+typedef struct xhe_verdict {
+    int32_t accept;        /* 1 = Ok(())                                                            */
+    int32_t err_code;      /* XHE_OK or XHE_ERR_*                                                   */
+    int64_t first_bad_tx;  /* index of the failing transaction, -1 when only the aggregate check failed */
+} xhe_verdict;
+
+/* Verifies the batch against the ledger snapshot `in` (BlockchainVerificationState of verify.rs:25-77,
+ * flattened).  On accept `out` (may be NULL) receives the ledger after all transactions were applied in
+ * order.  Differences from the reference, both documented in DESIGN.md: on reject `out` is not written
+ * (the reference leaves its state half-updated), and an unknown account or asset is XHE_ERR_STATE (the
+ * reference's mock ledger panics).  rng_seed seeds the batch-factor generator (the reference draws
+ * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it. */
+int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
+                         const xhe_ledger_view *in, const xhe_ledger_out *out, xhe_verdict *verdict,
+                         const uint8_t rng_seed[32]);
+
+/* The same verification on a batch already resident in HBM: xhe_batch_upload parses, checks and
+ * uploads the records and the ledger once; xhe_batch_verify runs only GPU work plus a 16-byte
+ * read-back.  xhe_batch_read_ledger copies the resulting ledger out after an accepting verify. */
+typedef struct xhe_batch xhe_batch;
+int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
+                         const xhe_ledger_view *in, xhe_batch **batch_out, xhe_verdict *structural_verdict);
+int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *batch, xhe_verdict *verdict, const uint8_t rng_seed[32]);
+int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *batch, const xhe_ledger_out *out);
+void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
+
+/* Per-stage GPU time of the last xhe_batch_verify / xhe_msm_vartime on this context, measured with HIP
+ * events on the context's stream.  names/ms arrays of length cap; returns the number of stages. */
+int32_t xhe_last_stage_times(const xhe_ctx *ctx, const char **names, float *ms, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XHE_H */

@@ -1,0 +1,88 @@
+"""Shared loaders for the test suite.
+
+The oracle (oracle/liboracle.so) is the CPU checker; tests/support/libxhe_host_primitives.so is a
+CPU build of the product's own arithmetic headers.  Both are built by __graft_entry__.build();
+neither is ever part of the shipped library."""
+import ctypes
+import os
+import random
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure(path, build_cmd, cwd):
+    if not os.path.exists(path):
+        subprocess.check_call(build_cmd, cwd=cwd, shell=True)
+    return ctypes.CDLL(path)
+
+
+def load_oracle():
+    lib = _ensure(os.path.join(ROOT, "oracle", "liboracle.so"), "make -s", os.path.join(ROOT, "oracle"))
+    lib.xo_merlin_script.restype = ctypes.c_uint64
+    lib.xo_tx_challenges.restype = ctypes.c_int64
+    lib.xo_bench_verify_batch.restype = ctypes.c_double
+    lib.xo_init()
+    return lib
+
+
+def load_host_primitives():
+    d = os.path.join(ROOT, "tests", "support")
+    cmd = ("g++ -O2 -std=c++17 -fPIC -shared -Wno-unknown-pragmas -o libxhe_host_primitives.so "
+           "xhe_host_primitives.cpp")
+    lib = _ensure(os.path.join(d, "libxhe_host_primitives.so"), cmd, d)
+    lib.xt_merlin_script.restype = ctypes.c_uint64
+    return lib
+
+
+def buf(n):
+    return (ctypes.c_uint8 * n)()
+
+
+def le32(x):
+    return int(x).to_bytes(32, "little")
+
+
+def from_le(b):
+    return int.from_bytes(bytes(b), "little")
+
+
+def merlin_script(ops):
+    """ops: list of ('A', label, data) / ('C', label, nbytes) -> byte script understood by *_merlin_script."""
+    out = b""
+    for op in ops:
+        if op[0] == "A":
+            out += b"A" + op[1] + b"\0" + len(op[2]).to_bytes(4, "little") + op[2]
+        else:
+            out += b"C" + op[1] + b"\0" + int(op[2]).to_bytes(4, "little")
+    return out
+
+
+def rng(seed):
+    return random.Random(seed)
+
+
+# ---- oracle-side verification of records built by the product's builder --------------------------------
+def oracle_verify_batch(oracle, txs, ledger, seed=b"\x07" * 32, single=False, apply_on_accept=True):
+    """Runs the CPU oracle's Transaction::verify_batch (or verify) on the Python Ledger mirror.
+    Returns (accept, err_code, first_bad_tx); on accept the ledger mirror is updated."""
+    from xelis_he_amd.api import LedgerOut, Verdict
+    f = ledger.flatten()
+    blob = b"".join(t.record for t in txs)
+    offs = [0]
+    for t in txs:
+        offs.append(offs[-1] + len(t.record))
+    offsets = (ctypes.c_uint64 * len(offs))(*offs)
+    out_cts = (ctypes.c_uint8 * max(64 * len(f["slots"]), 1))()
+    out_nonces = (ctypes.c_uint64 * max(len(f["keys"]), 1))()
+    ms_set = (ctypes.c_int64 * max(len(f["keys"]), 1))()
+    out = LedgerOut(out_cts, out_nonces, ms_set)
+    v = Verdict()
+    if single:
+        assert len(txs) == 1
+        oracle.xo_verify_single(blob, ctypes.c_uint64(len(blob)), ctypes.byref(f["view"]), ctypes.byref(out), ctypes.byref(v), seed)
+    else:
+        oracle.xo_verify_batch(blob, offsets, ctypes.c_uint64(len(txs)), ctypes.byref(f["view"]), ctypes.byref(out), ctypes.byref(v), seed)
+    if v.accept and apply_on_accept:
+        ledger.absorb(f, bytes(out_cts), list(out_nonces), list(ms_set), txs)
+    return bool(v.accept), v.err_code, v.first_bad_tx

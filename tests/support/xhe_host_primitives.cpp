@@ -1,0 +1,77 @@
+// CPU build of the product's host/device arithmetic headers (xelis-he_amd/csrc/xhe_*.h), exposed with
+// C linkage so the Python tests can compare them with the oracle and with hashlib on the CPU.
+// Test support only: the shipped library does not contain this file.
+#include <string.h>
+#include "../../xelis-he_amd/csrc/xhe_ge.h"
+#include "../../xelis-he_amd/csrc/xhe_hash.h"
+using namespace xhe;
+
+extern "C" {
+void xt_fe_mul(const u8 a[32], const u8 b[32], u8 out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); }
+void xt_fe_sq(const u8 a[32], u8 out[32]) { fe_tobytes(out, fe_sq(fe_frombytes(a))); }
+void xt_fe_invert(const u8 a[32], u8 out[32]) { fe_tobytes(out, fe_invert(fe_frombytes(a))); }
+// (a + b) * (a - b) exercises the lazy add/sub magnitudes
+void xt_fe_addsub_mul(const u8 a[32], const u8 b[32], u8 out[32]) {
+    fe x = fe_frombytes(a), y = fe_frombytes(b);
+    fe_tobytes(out, fe_mul(fe_add(x, y), fe_sub(x, y)));
+}
+void xt_fe_roundtrip(const u8 a[32], u8 out[32]) { fe_tobytes(out, fe_frombytes(a)); }
+void xt_sc_mul(const u8 a[32], const u8 b[32], u8 out[32]) { sc_tobytes(out, sc_mul(sc_frombytes(a), sc_frombytes(b))); }
+void xt_sc_add(const u8 a[32], const u8 b[32], u8 out[32]) { sc_tobytes(out, sc_add(sc_frombytes(a), sc_frombytes(b))); }
+void xt_sc_sub(const u8 a[32], const u8 b[32], u8 out[32]) { sc_tobytes(out, sc_sub(sc_frombytes(a), sc_frombytes(b))); }
+void xt_sc_invert(const u8 a[32], u8 out[32]) { sc_tobytes(out, sc_invert(sc_frombytes(a))); }
+void xt_sc_from_wide(const u8 a[64], u8 out[32]) { sc_tobytes(out, sc_from_wide_bytes(a)); }
+// sum of products with lazy additions: a*b + c*d + a*d
+void xt_sc_muladd(const u8 a[32], const u8 b[32], const u8 c[32], const u8 d[32], u8 out[32]) {
+    sc A = sc_frombytes(a), B = sc_frombytes(b), C = sc_frombytes(c), D = sc_frombytes(d);
+    sc r = sc_add(sc_add_lazy(sc_mul(A, B), sc_mul(C, D)), sc_mul(A, D));
+    sc_tobytes(out, r);
+}
+int xt_sc_canonical(const u8 a[32]) { u32 w[8]; memcpy(w, a, 32); return sc_words_canonical(w); }
+int xt_ristretto_decode(const u8 in[32], u8 out_xyzt[128]) {
+    ge p; bool ok = ristretto_decode(p, in);
+    fe_tobytes(out_xyzt, p.X); fe_tobytes(out_xyzt + 32, p.Y); fe_tobytes(out_xyzt + 64, p.Z); fe_tobytes(out_xyzt + 96, p.T);
+    return ok;
+}
+void xt_ristretto_encode(const u8 xyzt[128], u8 out[32]) {
+    ge p; p.X = fe_frombytes(xyzt); p.Y = fe_frombytes(xyzt + 32); p.Z = fe_frombytes(xyzt + 64); p.T = fe_frombytes(xyzt + 96);
+    ristretto_encode(out, p);
+}
+void xt_from_uniform_bytes(const u8 in[64], u8 out[32]) { ristretto_encode(out, ristretto_from_uniform_bytes(in)); }
+// out = enc(k*P) by double-and-add using ge_double/ge_add/ge_madd/ge_msub in rotation
+int xt_scalarmul(const u8 k[32], const u8 p32[32], u8 out[32]) {
+    ge p; if (!ristretto_decode(p, p32)) return -1;
+    ge_niels pn = ge_to_niels_affine(p);
+    ge r = ge_identity();
+    int flip = 0;
+    for (int i = 255; i >= 0; i--) {
+        r = ge_double(r);
+        if ((k[i >> 3] >> (i & 7)) & 1) {
+            switch (flip++ % 3) {
+                case 0: r = ge_add(r, p); break;
+                case 1: r = ge_madd(r, pn); break;
+                default: r = ge_madd_signed(ge_msub(ge_madd(r, pn), pn), pn, false); break;
+            }
+        }
+    }
+    ristretto_encode(out, r);
+    return 0;
+}
+void xt_sha3_512(const u8 *d, u32 n, u8 out[64]) { sha3_512(out, d, n); }
+void xt_sha3_256(const u8 *d, u32 n, u8 out[32]) { sha3_256(out, d, n); }
+void xt_shake256(const u8 *d, u32 n, u8 *out, u32 outlen) { sponge s; s.init(136, 0x1f); s.absorb(d, n); s.squeeze(out, outlen); }
+void xt_blake3(const u8 *d, u64 n, u8 out[32]) { blake3_hash(out, d, n); }
+u64 xt_merlin_script(const char *proto_label, const u8 *ops, u64 ops_len, u8 *out, u64 out_cap) {
+    transcript t; t.init(proto_label);
+    u64 pos = 0, w = 0;
+    while (pos < ops_len) {
+        char op = (char)ops[pos++];
+        const char *label = (const char *)(ops + pos);
+        pos += strlen(label) + 1;
+        u32 len; memcpy(&len, ops + pos, 4); pos += 4;
+        if (op == 'A') { t.append_message(label, ops + pos, len); pos += len; }
+        else { if (w + len > out_cap) return 0; t.challenge_bytes(label, out + w, len); w += len; }
+    }
+    return w;
+}
+}

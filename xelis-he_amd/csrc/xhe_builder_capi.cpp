@@ -1,0 +1,248 @@
+// C entry points of the transaction builder and of the synthetic-batch generator (include/xhe_builder.h).
+// CPU code: it produces inputs for the verification path (keys, ciphertexts, proofs, signatures,
+// ledgers) and never runs inside it.
+#include <string.h>
+#include <map>
+#include <thread>
+#include <atomic>
+#include "../../include/xhe_builder.h"
+#include "xhe_builder.h"
+#include "xhe_record.h"
+
+using namespace xhe;
+using namespace xhe::host;
+
+static bytes32 b32(const u8 *p) { bytes32 r; memcpy(r.data(), p, 32); return r; }
+static bytes64 b64(const u8 *p) { bytes64 r; memcpy(r.data(), p, 64); return r; }
+
+static int fill_builder(builder_in &in, const xhe_tx_request *rq) {
+    in.version = rq->version; in.type = rq->type; in.fee = rq->fee; in.nonce = rq->nonce;
+    for (u32 i = 0; i < rq->n_transfers; i++) {
+        transfer_in t; t.asset = b32(rq->transfer_assets + 32 * i); t.amount = rq->transfer_amounts[i]; t.dest = b32(rq->transfer_dests + 32 * i);
+        if (rq->transfer_extra && rq->transfer_extra_len && rq->transfer_extra_len[i]) t.extra_data.assign(rq->transfer_extra[i], rq->transfer_extra[i] + rq->transfer_extra_len[i]);
+        in.transfers.push_back(t);
+    }
+    in.burn_asset = b32(rq->burn_asset); in.burn_amount = rq->burn_amount;
+    for (u32 i = 0; i < rq->n_signers; i++) in.signers.push_back(b32(rq->signers + 32 * i));
+    in.threshold = rq->threshold;
+    in.contract = b32(rq->contract);
+    for (u32 i = 0; i < rq->n_contract_assets; i++) in.contract_assets.push_back({b32(rq->contract_assets + 32 * i), rq->contract_amounts[i]});
+    if (rq->opaque_len) in.opaque.assign(rq->opaque, rq->opaque + rq->opaque_len);
+    for (u32 i = 0; i < rq->n_balances; i++) { asset_balance b; b.asset = b32(rq->balance_assets + 32 * i); b.balance = rq->balance_amounts[i]; b.ct = b64(rq->balance_cts + 64 * i); in.balances.push_back(b); }
+    return 0;
+}
+
+extern "C" {
+
+int32_t xhe_keygen(const uint8_t secret32[32], uint8_t pub32[32]) {
+    if (!secret32 || !pub32 || !rec_scalar_canonical(secret32) || rec_is_zero32(secret32)) return -1;
+    keypair k = keypair::from_secret(sc_frombytes(secret32));
+    memcpy(pub32, k.pub_bytes.data(), 32);
+    return 0;
+}
+int32_t xhe_keygen_from_seed(const uint8_t seed32[32], uint8_t secret32[32], uint8_t pub32[32]) {
+    drbg rng(seed32);
+    sc s = rng.scalar();
+    sc_tobytes(secret32, s);
+    return xhe_keygen(secret32, pub32);
+}
+int32_t xhe_encrypt(const uint8_t pub32[32], uint64_t amount, const uint8_t seed32[32], uint8_t ct64[64]) {
+    ge pub; if (!ristretto_decode(pub, pub32)) return -1;
+    drbg rng(seed32);
+    bytes64 c = ct_bytes(encrypt(pub, amount, rng.scalar()));
+    memcpy(ct64, c.data(), 64);
+    return 0;
+}
+// decrypts to the point amount*G and compares (ElGamalSecretKey::decrypt, elgamal.rs:140-145): returns 1 on match
+int32_t xhe_ct_decrypts_to(const uint8_t secret32[32], const uint8_t ct64[64], uint64_t amount) {
+    ciphertext c; if (!ct_from_bytes(c, ct64)) return -1;
+    sc s = sc_frombytes(secret32);
+    ge pt = ge_sub(c.C, scalarmul(s, c.D));
+    return ge_ristretto_eq(pt, mul_G(sc_from_u64(amount))) ? 1 : 0;
+}
+int32_t xhe_sign(const uint8_t secret32[32], const uint8_t *msg, uint64_t n, const uint8_t seed32[32], uint8_t sig64[64]) {
+    keypair k = keypair::from_secret(sc_frombytes(secret32));
+    drbg rng(seed32);
+    bytes64 s = sign(k, msg, n, rng);
+    memcpy(sig64, s.data(), 64);
+    return 0;
+}
+int32_t xhe_signature_verify_host(const uint8_t sig64[64], const uint8_t *msg, uint64_t n, const uint8_t pub32[32]) {
+    return signature_verify_host(sig64, msg, n, pub32) ? 1 : 0;
+}
+
+// TransactionBuilder::build_unsigned.  The unsigned transaction is returned as a record with no
+// multisig entries and an all-zero signature.  new_balances (nullable): per emitted commitment
+// 32-byte asset || 8-byte LE balance || 64-byte ciphertext of the source after this transaction.
+int32_t xhe_tx_build_unsigned(const xhe_tx_request *rq, const uint8_t source_secret[32], const uint8_t seed32[32], uint8_t *out, uint64_t cap,
+                              uint64_t *out_len, uint8_t *new_balances, uint32_t *n_new_balances) {
+    if (!rq || !source_secret || !seed32 || !out_len) return -1;
+    builder_in in; fill_builder(in, rq);
+    keypair src = keypair::from_secret(sc_frombytes(source_secret));
+    drbg rng(seed32);
+    unsigned_tx u; std::vector<asset_balance> nb;
+    int rc = build_unsigned(in, src, rng, u, &nb);
+    if (rc) return 100 + rc;
+    std::vector<u8> rec = u.header;
+    rec.insert(rec.end(), u.preimage.begin(), u.preimage.end());
+    rec.resize(rec.size() + 64, 0);
+    *out_len = rec.size();
+    if (rec.size() > cap || !out) return -2;
+    memcpy(out, rec.data(), rec.size());
+    if (n_new_balances) *n_new_balances = (uint32_t)nb.size();
+    if (new_balances) for (size_t i = 0; i < nb.size(); i++) {
+        u8 *p = new_balances + 104 * i;
+        memcpy(p, nb[i].asset.data(), 32);
+        for (int k = 0; k < 8; k++) p[32 + k] = (u8)(nb[i].balance >> (8 * k));
+        memcpy(p + 40, nb[i].ct.data(), 64);
+    }
+    return 0;
+}
+// TransactionUnsigned::hash: BLAKE3 of the pre-image (without multisig entries and signature)
+int32_t xhe_tx_hash(const uint8_t *record, uint64_t len, uint8_t hash32[32]) {
+    tx_record t; if (!record_parse(t, record, len)) return -1;
+    blake3_hash(hash32, t.pre(), t.pre_len);
+    return 0;
+}
+// set_multisig + sign: rebuilds the record with the given multisig entries (ids[i], sigs[64*i]) and the
+// source's signature over pre-image || entries.  multisig_present = 0 leaves the field None.
+int32_t xhe_tx_finalize(const uint8_t *unsigned_record, uint64_t len, int32_t multisig_present, uint32_t n_multisig, const uint8_t *ids,
+                        const uint8_t *sigs, const uint8_t source_secret[32], const uint8_t seed32[32], uint8_t *out, uint64_t cap, uint64_t *out_len) {
+    tx_record t; if (!record_parse(t, unsigned_record, len) || t.n_multisig != 0) return -1;
+    unsigned_tx u;
+    u.header.assign(unsigned_record, unsigned_record + t.pre_off);
+    u.preimage.assign(t.pre(), t.pre() + t.pre_len);
+    u.has_multisig = multisig_present != 0;
+    for (u32 i = 0; i < n_multisig; i++) u.multisig.push_back({ids[i], b64(sigs + 64 * i)});
+    keypair src = keypair::from_secret(sc_frombytes(source_secret));
+    drbg rng(seed32);
+    std::vector<u8> rec = u.sign(src, rng);
+    *out_len = rec.size();
+    if (rec.size() > cap || !out) return -2;
+    memcpy(out, rec.data(), rec.size());
+    return 0;
+}
+
+// Transaction::apply_without_verify on the host (verify.rs:545-619): the prover's way to advance its
+// own copy of the ledger.  balance_cts is updated in place.  Returns 0, or -1 where the reference
+// would panic (unknown account/asset, ill-formed ciphertext).
+int32_t xhe_tx_apply_host(const uint8_t *record, uint64_t len, uint64_t n_accounts, const uint8_t *account_keys, uint64_t n_balances,
+                          const uint32_t *balance_account, const uint8_t *balance_assets, uint8_t *balance_cts) {
+    tx_record t; if (!record_parse(t, record, len)) return -1;
+    auto find_slot = [&](const u8 *account, const u8 *asset) -> int64_t {
+        for (u64 i = 0; i < n_balances; i++)
+            if (balance_account[i] < n_accounts && !memcmp(account_keys + 32 * balance_account[i], account, 32) && !memcmp(balance_assets + 32 * i, asset, 32)) return (int64_t)i;
+        return -1;
+    };
+    struct tp { ge C, Ds, Dr; };
+    std::vector<tp> pts(t.transfer_off.size());
+    for (size_t i = 0; i < pts.size(); i++) {
+        const u8 *p = t.transfer(i);
+        if (!ristretto_decode(pts[i].C, p + 64) || !ristretto_decode(pts[i].Ds, p + 96) || !ristretto_decode(pts[i].Dr, p + 128)) return -1;
+    }
+    for (u32 i = 0; i < t.n_commitments; i++) {
+        const u8 *asset = t.commitment(i);
+        int64_t slot = find_slot(t.source(), asset);
+        if (slot < 0) return -1;
+        ciphertext cur; if (!ct_from_bytes(cur, balance_cts + 64 * slot)) return -1;
+        bool of; u64 plain = record_plain_output(t, asset, &of);
+        if (of) return -1;
+        cur.C = ge_sub(cur.C, mul_G(sc_from_u64(plain)));
+        for (size_t k = 0; k < pts.size(); k++) if (!memcmp(asset, t.transfer(k), 32)) { cur.C = ge_sub(cur.C, pts[k].C); cur.D = ge_sub(cur.D, pts[k].Ds); }
+        bytes64 nb = ct_bytes(cur); memcpy(balance_cts + 64 * slot, nb.data(), 64);
+    }
+    for (size_t k = 0; k < pts.size(); k++) {
+        const u8 *p = t.transfer(k);
+        int64_t slot = find_slot(p + 32, p);
+        if (slot < 0) return -1;
+        ciphertext cur; if (!ct_from_bytes(cur, balance_cts + 64 * slot)) return -1;
+        cur.C = ge_add(cur.C, pts[k].C); cur.D = ge_add(cur.D, pts[k].Dr);
+        bytes64 nb = ct_bytes(cur); memcpy(balance_cts + 64 * slot, nb.data(), 64);
+    }
+    return 0;
+}
+
+// ---- synthetic batches (benches/tx.rs:129-189 generalised) -------------------------------------------
+struct xhe_synth {
+    std::vector<u8> records; std::vector<u64> offsets;
+    std::vector<u8> account_keys; std::vector<u64> nonces;
+    std::vector<u32> balance_account; std::vector<u8> balance_assets, balance_cts;
+    std::vector<u8> secrets;
+    xhe_ledger_view view;
+};
+
+// n_txs transfers-only transactions of n_transfers transfers each (amount 1, fee 3, nonce 0, native
+// asset), spread round-robin over n_senders sender accounts funded with 10^7, each with its own
+// receiver; every transaction is built against the ledger left by the previous transaction of its
+// sender.  Commitments and ciphertext chains are laid out sequentially per sender (cheap), the proofs
+// are generated by `threads` workers.
+xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads) {
+    if (!n_senders || !n_transfers || n_transfers > 255 || !seed32) return nullptr;
+    if (threads < 1) threads = 1;
+    xhe_synth *S = new xhe_synth();
+    drbg root(seed32);
+    const u64 FUNDS = 10000000;
+    std::vector<keypair> senders(n_senders), receivers(n_senders);
+    std::vector<bytes64> sender_ct(n_senders);
+    std::vector<u64> sender_bal(n_senders, FUNDS);
+    S->account_keys.resize(64ull * n_senders); S->nonces.assign(2ull * n_senders, 0);
+    S->balance_account.resize(2ull * n_senders); S->balance_assets.assign(64ull * n_senders, 0); S->balance_cts.resize(128ull * n_senders);
+    S->secrets.resize(64ull * n_senders);
+    for (u32 i = 0; i < n_senders; i++) {
+        senders[i] = keypair::from_secret(root.scalar()); receivers[i] = keypair::from_secret(root.scalar());
+        sc_tobytes(&S->secrets[64 * i], senders[i].secret); sc_tobytes(&S->secrets[64 * i + 32], receivers[i].secret);
+        memcpy(&S->account_keys[64 * i], senders[i].pub_bytes.data(), 32);
+        memcpy(&S->account_keys[64 * i + 32], receivers[i].pub_bytes.data(), 32);
+        sender_ct[i] = ct_bytes(encrypt(senders[i].pub, FUNDS, root.scalar()));
+        bytes64 rc = ct_bytes(encrypt(receivers[i].pub, 0, root.scalar()));
+        S->balance_account[2 * i] = 2 * i; S->balance_account[2 * i + 1] = 2 * i + 1;
+        memcpy(&S->balance_cts[128 * i], sender_ct[i].data(), 64); memcpy(&S->balance_cts[128 * i + 64], rc.data(), 64);
+    }
+    // per-transaction seeds and per-sender chains; a sender's transactions are proved in order by one
+    // worker, different senders in parallel.  With a single sender the chain is still sequential in the
+    // ciphertext but each proof only needs the ciphertext, so transactions are first "planned" (the
+    // builder is run once per tx in order inside the worker that owns the sender).
+    std::vector<std::vector<u8>> recs(n_txs);
+    std::vector<bytes32> seeds(n_txs);
+    for (u64 k = 0; k < n_txs; k++) { u8 s[32]; root.bytes(s, 32); seeds[k] = b32(s); }
+    std::atomic<u32> next_sender(0); std::atomic<int> failed(0);
+    auto worker = [&]() {
+        for (;;) {
+            u32 s = next_sender.fetch_add(1);
+            if (s >= n_senders) break;
+            for (u64 k = s; k < n_txs; k += n_senders) {
+                builder_in in; in.version = 1; in.type = 0; in.fee = 3; in.nonce = 0;
+                for (u32 j = 0; j < n_transfers; j++) { transfer_in tr; tr.asset = bytes32{}; tr.amount = 1; tr.dest = receivers[s].pub_bytes; in.transfers.push_back(tr); }
+                asset_balance b; b.asset = bytes32{}; b.balance = sender_bal[s]; b.ct = sender_ct[s]; in.balances.push_back(b);
+                drbg rng(seeds[k].data());
+                unsigned_tx u; std::vector<asset_balance> nb;
+                if (build_unsigned(in, senders[s], rng, u, &nb) != BUILD_OK) { failed = 1; return; }
+                recs[k] = u.sign(senders[s], rng);
+                sender_bal[s] = nb[0].balance; sender_ct[s] = nb[0].ct;
+            }
+        }
+    };
+    gens().ensure(64 * 2);   // touch the lazily built tables before the workers start
+    {
+        u32 m = 1; while (m < n_transfers + 1) m <<= 1;
+        gens().ensure(64ull * m);
+    }
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+    for (auto &th : pool) th.join();
+    if (failed) { delete S; return nullptr; }
+    S->offsets.push_back(0);
+    for (u64 k = 0; k < n_txs; k++) { S->records.insert(S->records.end(), recs[k].begin(), recs[k].end()); S->offsets.push_back(S->records.size()); }
+    xhe_ledger_view &v = S->view;
+    memset(&v, 0, sizeof v);
+    v.n_accounts = 2ull * n_senders; v.account_keys = S->account_keys.data(); v.account_nonces = S->nonces.data();
+    v.n_balances = 2ull * n_senders; v.balance_account = S->balance_account.data(); v.balance_assets = S->balance_assets.data(); v.balance_cts = S->balance_cts.data();
+    return S;
+}
+void xhe_synth_free(xhe_synth *s) { delete s; }
+const uint8_t *xhe_synth_records(const xhe_synth *s, uint64_t *len) { if (len) *len = s->records.size(); return s->records.data(); }
+const uint64_t *xhe_synth_offsets(const xhe_synth *s, uint64_t *n_txs) { if (n_txs) *n_txs = s->offsets.size() - 1; return s->offsets.data(); }
+const xhe_ledger_view *xhe_synth_ledger(const xhe_synth *s) { return &s->view; }
+const uint8_t *xhe_synth_secrets(const xhe_synth *s) { return s->secrets.data(); }
+
+}  // extern "C"
