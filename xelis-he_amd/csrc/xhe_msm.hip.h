@@ -114,8 +114,10 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const u32 *__restrict__ sca
 }
 
 // thread per bucket
-__global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ offsets,
-                                                           const u32 *__restrict__ sorted, u32 n_buckets, u32 *__restrict__ bucket_sums) {
+// term_point (nullable): term index -> record index in niels[]; n_points bounds the gather
+__global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
+                                                           const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets,
+                                                           u32 *__restrict__ bucket_sums) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_buckets) return;
     u32 lo = offsets[g], hi = offsets[g + 1];
@@ -124,6 +126,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict
         u32 e = sorted[k];
         u32 idx = e & 0x7fffffffu;
         if (idx >= n) continue;                       // never taken for a consistent index; guards the gather
+        if (term_point) { idx = term_point[idx]; if (idx >= n_points) continue; }
         ge_niels q = ge_niels_load(niels + 32ull * idx);
         acc = ge_madd_signed(acc, q, (e >> 31) != 0);
     }

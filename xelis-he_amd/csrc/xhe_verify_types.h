@@ -1,0 +1,90 @@
+// Device-resident tables of one uploaded batch: what the host ingest (xhe_ingest.h) lays out and the
+// verification kernels (xhe_verify.hip.h) consume.  All offsets into `bytes` are absolute byte offsets
+// into one device byte buffer holding the transaction records followed by the ledger's account keys,
+// balance ciphertexts and multisig signer keys.
+//
+// Error precedence of Transaction::pre_verify (/root/reference/src/tx/verify.rs:203-485) is carried as a
+// 32-bit key per transaction, smaller = earlier: [31:28] stage, [27:12] index, [11:8] sub-stage,
+// [7:0] error code.  Every kernel that detects a failure does atomicMin on the transaction's key.
+#pragma once
+#include <stdint.h>
+#include "xhe_fe.h"
+
+namespace xhe {
+
+static constexpr u32 ERRKEY_NONE = 0xffffffffu;
+XHE_HD u32 errkey(u32 stage, u32 index, u32 sub, u32 code) { return (stage << 28) | ((index & 0xffffu) << 12) | ((sub & 15u) << 8) | (code & 0xffu); }
+enum : u32 {
+    ST_NONCE = 0, ST_ASSETS = 1, ST_DECOMPRESS = 2, ST_SIGNATURE = 5, ST_MULTISIG = 6, ST_COMMITMENT = 7, ST_TRANSFER = 8, ST_TYPE_FORMAT = 9
+};
+
+// one per transaction
+struct dev_tx {
+    u64 rec;                 // record start in bytes[]
+    u32 pre_off, pre_len;    // signing pre-image (without multisig entries), relative to rec
+    u32 payload_off, rp_off, cm_off, ms_off, sig_off;
+    u32 xfer_first;          // index of the first transfer of this tx in dev_xfer[]
+    u32 cm_first;            // index of the first commitment of this tx in dev_cm[]
+    u16 n_transfers, n_commitments, n_multisig, n_items;
+    u8 type, lg, version, flags;
+    u32 m;                   // value commitments of the range proof (power of two)
+    u64 fee, nonce;
+    u32 chal_off;            // first challenge of this tx in chal[]: (c,w) per commitment, (c,w) per transfer, y,z,x,w,u_1..u_lg
+    u32 rp_term_off;         // first MSM term of the range proof: A,S,T1,T2,L..,R..,V.. (real commitments only)
+    u32 rp_pt;               // point index of A (S,T_1,T_2,L_0,R_0,L_1,... follow)
+    u32 src_pt;              // point index of the source key
+    u32 hash_idx;            // index into ms_hash[] (BLAKE3 of the pre-image) or 0xffffffff
+    u32 rp_row;              // row of this tx inside its nm-group's scalar matrix
+    u32 reserved;
+};
+
+// one per new source commitment (CommitmentEqProof)
+struct dev_cm {
+    u32 tx, idx;
+    u64 off;                 // asset[32], commitment[32], Y_0,Y_1,Y_2,z_s,z_x,z_r -- absolute offset in bytes[]
+    u32 pt;                  // point index of C_new, then Y_0, Y_1, Y_2
+    u32 src_ct_pt;           // point index of the sender's new ciphertext C (D follows), produced by the ledger scan
+    u32 term_off;            // 7 MSM terms
+    u32 slot_pt;             // point index of the slot's initial ciphertext C (D follows)
+    u32 first_touch;         // 1 if this commitment is the first reader of the slot's initial value
+};
+
+// one per transfer (CiphertextValidityProof)
+struct dev_xfer {
+    u32 tx, idx;
+    u64 off;                 // asset, dest, C, D_s, D_r, [extra], proof -- absolute offset of the transfer
+    u64 proof_off;           // absolute offset of Y_0,Y_1,Y_2,z_r,z_x
+    u32 pt;                  // point index of C, then D_s, D_r, Y_0, Y_1, Y_2
+    u32 dest_pt;             // point index of the destination key (0xffffffff: account unknown to the ledger)
+    u32 term_off;            // 8 MSM terms
+    u32 slot_pt;             // receiver slot's initial ciphertext
+    u32 first_touch;
+    u32 state_err;           // 1: receiver account/asset missing in the ledger
+};
+
+// one per point to decode
+struct dev_dec { u64 off; };
+
+// ledger scan: elementary operations sorted by (slot, order)
+struct dev_op {
+    u32 slot;
+    u32 kind;                // 0: +point pair, 1: -point pair, 2: -(amount*G) on the commitment only
+    u32 c_pt, d_pt;          // point indices (kind 0/1)
+    u64 amount;              // kind 2
+    u32 emit;                // 0xffffffff, or index into the emitted ciphertext list (sender's new balance)
+    u32 first;               // 1: first operation of its slot (the initial balance)
+};
+
+// one per signature to verify
+struct dev_sig {
+    u32 tx;
+    u32 key_pt;              // decoded public key
+    u64 key_off;             // its 32 bytes
+    u64 msg_off; u32 msg_len;  // message bytes in bytes[] ...
+    u32 hash_idx;            // ... or, if != 0xffffffff, the 32-byte BLAKE3 digest ms_hash[hash_idx]
+    u64 sig_off;             // s || e
+    u32 err_key;             // key raised when the signature does not verify
+    u32 key_err_key;         // key raised when the public key does not decode (0 = checked elsewhere)
+};
+
+}  // namespace xhe
