@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Transaction::verify_batch on MI355X.
+
+A step is one verification of one synthetic batch that is already resident in HBM
+(xhe_batch_upload once, then xhe_batch_verify per step).  The workload is BASELINE.json's configs[1]:
+a 10 000-transaction batch, 1 transfer each, single (native) asset, per GPU.  With --gpus N every rank
+verifies its own batch (transactions shard by account group, no data-path collective) and the ranks
+AND-reduce their accept bits with one RCCL all-reduce (MIN) per step; value = transactions of all ranks
+/ max-over-ranks time (weak scaling).
+
+Prints one JSON line (rank 0).  roofline: the dominant kernel is the bucket accumulation of the
+Pippenger multiscalar check; `achieved` = algorithmic bytes of the whole multiscalar check / that
+kernel's average launch time, measured with HIP events on the library's stream.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--txs", type=int, default=10000, help="transactions per GPU batch")
+    ap.add_argument("--transfers", type=int, default=1)
+    ap.add_argument("--senders", type=int, default=1024, help="sender accounts per batch (1 = the reference bench's single chain)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="transactions of the batch the CPU baseline verifies (0 = skip)")
+    ap.add_argument("--gen-threads", type=int, default=16)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the verification path")
+    torch.cuda.set_device(local_rank)
+
+    import xelis_he_amd
+    from xelis_he_amd.api import SyntheticBatch, Verdict, _lib
+    lib = _lib()
+    lib.xhe_batch_upload.restype = ctypes.c_int32
+    lib.xhe_batch_verify.restype = ctypes.c_int32
+    engine = xelis_he_amd.Engine(local_rank)
+
+    t0 = time.time()
+    senders = min(args.senders, args.txs)
+    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads)
+    gen_s = time.time() - t0
+
+    handle = ctypes.c_void_p()
+    sv = Verdict()
+    t0 = time.time()
+    engine._check(lib.xhe_batch_upload(ctypes.c_void_p(engine.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view,
+                                       ctypes.byref(handle), ctypes.byref(sv)))
+    upload_s = time.time() - t0
+    assert sv.accept == 1, "synthetic batch is malformed"
+
+    verdict = Verdict()
+    flag = torch.ones(1, dtype=torch.int64, device="cuda")
+
+    def step(i):
+        seed = (i + 1).to_bytes(8, "little") * 4
+        engine._check(lib.xhe_batch_verify(ctypes.c_void_p(engine.ctx), handle, ctypes.byref(verdict), seed))
+        ok = verdict.accept
+        if dist is not None:
+            flag.fill_(ok)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # AND of the per-shard accept bits
+            ok = int(flag.item())
+        return ok
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        assert step(i) == 1, "verification rejected a valid batch"
+    stage_sum, stage_n = {}, 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        assert step(args.warmup + i) == 1, "verification rejected a valid batch"
+        for name, ms in engine.stage_times():
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        stage_n += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    stages = {k: v / max(stage_n, 1) for k, v in stage_sum.items()}
+    # algorithmic bytes of the multiscalar check: per dynamic term a 32-byte scalar + a 128-byte decoded
+    # point record, per static generator the same, 32 bytes of result
+    T, A = args.transfers, 1
+    m = 1
+    while m < A + T:
+        m *= 2
+    lg = 6 + (m.bit_length() - 1)
+    dyn_terms = args.txs * (7 * A + 8 * T + 4 + 2 * lg + A + T)
+    static_terms = 2 + 2 * 64 * m
+    algo_bytes = (dyn_terms + static_terms) * 160 + 32
+    acc_ms = stages.get("msm_accumulate", 0.0)
+    roofline = None
+    if acc_ms > 0:
+        achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                    "traffic": None, "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": algo_bytes}
+
+    cpu_baseline = None
+    if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers
+        oracle = helpers.load_oracle()
+        n_s = min(args.cpu_sample, batch.n_txs)
+        cores = min(os.cpu_count() or 1, 16)
+        ok = ctypes.c_int32()
+        sec = oracle.xo_bench_verify_batch(batch.records, batch.offsets, ctypes.c_uint64(n_s), batch.view, cores, ctypes.byref(ok))
+        if ok.value == 1 and sec > 0:
+            one = oracle.xo_bench_verify_batch(batch.records, batch.offsets, ctypes.c_uint64(min(n_s, 256)), batch.view, 1, ctypes.byref(ok))
+            cpu_baseline = {"value": round(cores * n_s / sec, 1), "unit": "tx/s", "cores": cores, "kind": "port",
+                            "sample": "first %d transactions of the batch, one ledger clone per thread, %d threads (benches/tx.rs:307-325 style)" % (n_s, cores),
+                            "single_thread_ms_per_tx": round(one / min(n_s, 256) * 1e3, 4), "reference_published_ms_per_tx": 0.40}
+
+    if rank == 0:
+        total_txs = args.txs * args.gpus * args.steps
+        out = {
+            "metric": "verified tx/sec (batched)", "value": round(total_txs / elapsed, 1), "unit": "tx/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
+                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "setup": {"generate_s": round(gen_s, 2), "parse_upload_s": round(upload_s, 4)},
+        }
+        print(json.dumps(out), flush=True)
+    lib.xhe_batch_free(ctypes.c_void_p(engine.ctx), handle)
+    engine.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -176,8 +176,16 @@ static inline int range_proof_terms(rp_terms &out, const u8 *proof, size_t proof
         if (!t.validate_and_append_point("R", LR + 64 * i + 32)) return XO_ERR_RANGE_PROOF;
         u[i] = t.challenge_scalar("u");
     }
-    sc allinv = sc_one();
-    for (size_t i = 0; i < lg; i++) { u_inv[i] = sc_invert(u[i]); allinv = sc_mul(allinv, u_inv[i]); }
+    // Scalar::batch_invert: one inversion for all challenges (Montgomery's trick)
+    sc allinv;
+    {
+        std::vector<sc> pre(lg + 1);
+        pre[0] = sc_one();
+        for (size_t i = 0; i < lg; i++) pre[i + 1] = sc_mul(pre[i], u[i]);
+        sc inv = sc_invert(pre[lg]);
+        allinv = inv;
+        for (size_t i = lg; i-- > 0;) { u_inv[i] = sc_mul(inv, pre[i]); inv = sc_mul(inv, u[i]); }
+    }
     std::vector<sc> u_sq(lg), u_inv_sq(lg);
     for (size_t i = 0; i < lg; i++) { u_sq[i] = sc_mul(u[i], u[i]); u_inv_sq[i] = sc_mul(u_inv[i], u_inv[i]); }
     std::vector<sc> s(nm);

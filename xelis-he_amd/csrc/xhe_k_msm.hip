@@ -1,0 +1,344 @@
+// Pippenger bucket multiscalar multiplication for gfx950: the kernels behind
+// RistrettoPoint::vartime_multiscalar_mul (/root/reference/src/proofs.rs:49-67) and the range-proof
+// mega-check (/root/reference/src/tx/verify.rs:504-513).
+//
+// Pipeline (every stage one launch over the whole problem):
+//   digits+histogram  thread per term: signed radix-2^c digits, one atomic count per (window, bucket)
+//   scan              exclusive prefix sum of the W*B counters
+//   scatter           thread per term: term index (+sign bit) written into its bucket's segment
+//   accumulate        thread per chunk of M consecutive entries of the bucket-sorted array: mixed additions of
+//                     the entries' affine-Niels points; buckets that lie inside the chunk are finished there,
+//                     the (at most two) buckets cut by the chunk's borders leave partial sums
+//   merge             thread per bucket: adds the partial sums of a bucket cut by chunk borders; buckets
+//                     spanning many chunks (the top window holds only the digit carry, so half of all terms
+//                     meet in one bucket) go to a workgroup-per-bucket reduction instead
+//   reduce            wave per (window, 64*L buckets): running sums per lane, then lane-weighted sums
+//                     with wavefront shuffles
+//   window combine    wave per window over the segment partials (same shuffle scheme)
+//   horner            the 253 doublings over the window sums, compress, identity test
+// Points come in as 128-byte affine-Niels records (xhe_ge.h), scalars as canonical 32-byte values.
+// The work per thread of the accumulate stage is M additions whatever the distribution of the digits.
+#include "xhe_dev_common.h"
+#include "xhe_kernels.h"
+
+namespace xhe {
+
+// window width by term count: balances n*W bucket additions against 2*W*B reduction additions and
+// keeps W*B large enough to occupy the 256 CUs
+msm_plan msm_make_plan(u64 n) {
+    u32 c;
+    if (n < 256) c = 7;
+    else if (n < 4096) c = 8;
+    else if (n < 32768) c = 10;
+    else if (n < 200000) c = 12;
+    else if (n < 1500000) c = 14;
+    else if (n < 6000000) c = 15;
+    else c = 16;
+    msm_plan p;
+    p.c = c; p.W = 253 / c + 1; p.B = 1u << (c - 1);
+    u32 L = p.B / 4096; if (L < 1) L = 1;          // S = B/(64L) <= 64
+    if (p.B < 64) L = 1;
+    p.L = L; p.S = (p.B + 64 * L - 1) / (64 * L);
+    u64 entries = n * p.W;
+    p.M = entries < (1u << 16) ? 8 : entries < (1u << 20) ? 16 : 32;
+    return p;
+}
+
+static constexpr u32 MERGE_SPAN_MAX = 8;     // a bucket cut into more chunks than this is reduced by a workgroup
+
+static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return (e + p.M - 1) / p.M + 1; }
+
+msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
+    u64 nb = (u64)p.W * p.B, entries = n * p.W, chunks = msm_chunks(n, p);
+    msm_ws_bytes b;
+    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.cursor = nb * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
+    b.chunk_bucket = 64;                       // unused slot kept for layout stability
+    b.chunk_sums = chunks * 2 * 128; b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
+    b.segs = (u64)p.W * p.S * 2 * 128; b.wins = (u64)p.W * 128;
+    return b;
+}
+
+// thread per term: signed radix-2^c digits of a canonical scalar (eight words), each in
+// [-(2^(c-1)-1), 2^(c-1)], serial carry from the least significant window
+template <typename F>
+__device__ __forceinline__ void msm_for_each_digit(const u32 s[8], u32 c, u32 W, F f) {
+    u32 carry = 0;
+    const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
+    for (u32 w = 0; w < W; w++) {
+        u32 bit = w * c, word = bit >> 5, off = bit & 31;
+        u32 raw = 0;
+        if (word < 8) {
+            u64 two = (u64)s[word] | ((word + 1 < 8) ? ((u64)s[word + 1] << 32) : 0);
+            raw = (u32)(two >> off) & mask;
+        }
+        u32 v = raw + carry;
+        int d;
+        if (v > half) { d = (int)v - (int)(1u << c); carry = 1; } else { d = (int)v; carry = 0; }
+        f(w, d);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_msm_histogram(const u32 *__restrict__ scalars, u64 n, msm_plan p, u32 *__restrict__ hist) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 s[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
+    msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
+        if (d != 0) { u32 a = d < 0 ? (u32)(-d) : (u32)d; atomicAdd(&hist[(u64)w * p.B + (a - 1)], 1u); }
+    });
+}
+
+// single workgroup exclusive scan of `count` counters into offsets[count + 1]; cursor = copy of offsets
+__global__ void __launch_bounds__(1024) k_msm_scan(const u32 *__restrict__ hist, u32 count, u32 *__restrict__ offsets, u32 *__restrict__ cursor) {
+    __shared__ u32 part[1024];
+    u32 t = threadIdx.x;
+    u32 per = (count + 1023) / 1024;
+    u32 lo = t * per, hi = lo + per; if (hi > count) hi = count; if (lo > count) lo = count;
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += hist[i];
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = (t == 0) ? 0 : part[t - 1];
+    for (u32 i = lo; i < hi; i++) { offsets[i] = run; cursor[i] = run; run += hist[i]; }
+    if (t == 1023) offsets[count] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_msm_scatter(const u32 *__restrict__ scalars, u64 n, msm_plan p, u32 *__restrict__ cursor,
+                                                     u32 *__restrict__ sorted, u64 sorted_cap) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 s[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
+    msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
+        if (d != 0) {
+            u32 a = d < 0 ? (u32)(-d) : (u32)d;
+            u32 pos = atomicAdd(&cursor[(u64)w * p.B + (a - 1)], 1u);
+            if (pos < sorted_cap) sorted[pos] = (u32)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    });
+}
+__device__ __forceinline__ ge ge_shfl_down(const ge &p, u32 delta) {
+    ge r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        r.X.v[i] = __shfl_down(p.X.v[i], delta, 64); r.Y.v[i] = __shfl_down(p.Y.v[i], delta, 64);
+        r.Z.v[i] = __shfl_down(p.Z.v[i], delta, 64); r.T.v[i] = __shfl_down(p.T.v[i], delta, 64);
+    }
+    return r;
+}
+__device__ __forceinline__ ge ge_select(const ge &a, const ge &b, bool flag) {
+    ge r; r.X = fe_select(a.X, b.X, flag); r.Y = fe_select(a.Y, b.Y, flag); r.Z = fe_select(a.Z, b.Z, flag); r.T = fe_select(a.T, b.T, flag);
+    return r;
+}
+
+
+// Thread per chunk [t*M, (t+1)*M) of the bucket-sorted entries.  term_point (nullable): term index ->
+// record index in niels[]; n_points bounds the gather.  chunk_sums[2t] = partial sum of the bucket that
+// began before the chunk, chunk_sums[2t+1] = partial sum of the bucket that continues after it.
+__global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
+                                                           const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets, u32 M,
+                                                           u32 *__restrict__ bucket_sums, u32 *__restrict__ chunk_sums) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = offsets[n_buckets];
+    u64 start64 = (u64)t * M;
+    if (start64 >= total) return;
+    u32 start = (u32)start64, stop = (total - start < M) ? total : start + M;
+    // the bucket holding `start`: the largest b with offsets[b] <= start (empty buckets share an offset)
+    u32 lo = 0, hi = n_buckets;
+    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (offsets[mid] <= start) lo = mid; else hi = mid; }
+    u32 b = lo, bend = offsets[b + 1];
+    bool began_before = offsets[b] < start;
+    ge acc = ge_identity();
+    for (u32 k = start; k < stop; k++) {
+        if (k >= bend) {                              // bucket b ended exactly at k
+            ge_store(began_before ? chunk_sums + 64ull * t : bucket_sums + 32ull * b, acc);
+            acc = ge_identity(); began_before = false;
+            do { b++; bend = offsets[b + 1]; } while (k >= bend);     // b < n_buckets since k < total
+        }
+        u32 e = sorted[k];
+        u32 idx = e & 0x7fffffffu;
+        if (idx >= n) continue;                       // never taken for a consistent index; guards the gather
+        if (term_point) { idx = term_point[idx]; if (idx >= n_points) continue; }
+        ge_niels q = ge_niels_load(niels + 32ull * idx);
+        acc = ge_madd_signed(acc, q, (e >> 31) != 0);
+    }
+    u32 *dst;
+    if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
+    else if (bend <= stop) dst = bucket_sums + 32ull * b;            // the bucket is complete inside the chunk
+    else dst = chunk_sums + 64ull * t + 32;
+    ge_store(dst, acc);
+}
+
+// thread per bucket: empty buckets get the identity, buckets inside one chunk are already final, the others
+// add their partial sums.  big_list[0] counts the buckets deferred to k_msm_merge_big, ids from big_list[1].
+__global__ void __launch_bounds__(256, 2) k_msm_merge(const u32 *__restrict__ offsets, u32 n_buckets, u32 M, const u32 *__restrict__ chunk_sums,
+                                                      u32 *__restrict__ bucket_sums, u32 *__restrict__ big_list, u32 big_cap) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_buckets) return;
+    u32 lo = offsets[g], hi = offsets[g + 1];
+    if (lo == hi) { ge_store(bucket_sums + 32ull * g, ge_identity()); return; }
+    u32 c0 = lo / M, c1 = (hi - 1) / M;
+    if (c0 == c1) return;
+    if (c1 - c0 > MERGE_SPAN_MAX) {
+        u32 pos = atomicAdd(&big_list[0], 1u);
+        if (pos < big_cap) big_list[1 + pos] = g;
+        return;
+    }
+    ge acc = ge_load(chunk_sums + 64ull * c0 + 32);        // the first chunk holds it as its trailing partial
+    for (u32 c = c0 + 1; c <= c1; c++) acc = ge_add(acc, ge_load(chunk_sums + 64ull * c));
+    ge_store(bucket_sums + 32ull * g, acc);
+}
+
+// workgroup per deferred bucket (grid-stride over the list): threads add the chunk partials with stride
+// 256, waves fold with shuffles, LDS joins the four waves
+__global__ void __launch_bounds__(256, 2) k_msm_merge_big(const u32 *__restrict__ offsets, u32 M, const u32 *__restrict__ chunk_sums, u32 *__restrict__ bucket_sums,
+                                                          const u32 *__restrict__ big_list, u32 big_cap) {
+    __shared__ u32 part[3][40];
+    u32 count = big_list[0]; if (count > big_cap) count = big_cap;
+    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 bi = blockIdx.x; bi < count; bi += gridDim.x) {
+        u32 g = big_list[1 + bi];
+        u32 lo = offsets[g], hi = offsets[g + 1];
+        u32 c0 = lo / M, c1 = (hi - 1) / M;
+        ge acc = ge_identity();
+        if (threadIdx.x == 0) acc = ge_load(chunk_sums + 64ull * c0 + 32);
+        for (u32 c = c0 + 1 + threadIdx.x; c <= c1; c += 256) acc = ge_add(acc, ge_load(chunk_sums + 64ull * c));
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) {
+            ge o = ge_shfl_down(acc, d);
+            ge sum = ge_add(acc, o);
+            acc = ge_select(acc, sum, lane < d);
+        }
+        __syncthreads();                              // previous iteration's readers are done with part[]
+        if (lane == 0 && wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) { part[wave - 1][i] = acc.X.v[i]; part[wave - 1][10 + i] = acc.Y.v[i]; part[wave - 1][20 + i] = acc.Z.v[i]; part[wave - 1][30 + i] = acc.T.v[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 0; w < 3; w++) {
+                ge o;
+#pragma unroll
+                for (int i = 0; i < 10; i++) { o.X.v[i] = part[w][i]; o.Y.v[i] = part[w][10 + i]; o.Z.v[i] = part[w][20 + i]; o.T.v[i] = part[w][30 + i]; }
+                acc = ge_add(acc, o);
+            }
+            ge_store(bucket_sums + 32ull * g, acc);
+        }
+    }
+}
+
+// Given per-lane (T, U): returns in lane 0  sum_l U_l + mult * sum_l l * T_l, and the plain sum of T
+// in t_total (lane 0).  mult is a power of two (log2_mult doublings).
+__device__ __forceinline__ ge wave_weighted_sum(const ge &T, const ge &U, u32 log2_mult, ge &t_total) {
+    u32 lane = threadIdx.x & 63;
+    // inclusive suffix scan of T: S_l = sum_{k >= l} T_k
+    ge S = T;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        ge o = ge_shfl_down(S, d);
+        ge sum = ge_add(S, o);
+        S = ge_select(S, sum, lane + d < 64);
+    }
+    t_total = S;                                       // lane 0 holds the total
+    // sum_l l*T_l = sum_{k=1..63} S_k
+    ge Q = ge_select(S, ge_identity(), lane == 0);
+    for (u32 k = 0; k < log2_mult; k++) Q = ge_double(Q);
+    Q = ge_add(Q, U);
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) {
+        ge o = ge_shfl_down(Q, d);
+        ge sum = ge_add(Q, o);
+        Q = ge_select(Q, sum, lane < d);
+    }
+    return Q;
+}
+
+// one wave per (window, segment of 64*L buckets): writes T (plain sum) and V (sum weighted by the
+// position inside the segment, 1-based) to seg_out[(w*S + s)*2 + {0,1}]
+__global__ void __launch_bounds__(64) k_msm_reduce_segments(const u32 *__restrict__ bucket_sums, msm_plan p, u32 *__restrict__ seg_out) {
+    u32 w = blockIdx.x / p.S, s = blockIdx.x % p.S;
+    u32 lane = threadIdx.x;
+    u32 base = s * 64 * p.L + lane * p.L;             // first bucket index (0-based) of this lane
+    ge run = ge_identity(), usum = ge_identity();
+    for (int j = (int)p.L - 1; j >= 0; j--) {
+        u32 b = base + (u32)j;
+        if (b < p.B) run = ge_add(run, ge_load(bucket_sums + 32ull * ((u64)w * p.B + b)));
+        usum = ge_add(usum, run);
+    }
+    u32 log2L = 0; while ((1u << log2L) < p.L) log2L++;
+    ge total;
+    ge V = wave_weighted_sum(run, usum, log2L, total);
+    if (lane == 0) {
+        u64 o = ((u64)w * p.S + s) * 2;
+        ge_store(seg_out + 32 * o, total);
+        ge_store(seg_out + 32 * (o + 1), V);
+    }
+}
+
+// one wave per window over its S <= 64 segments: window sum = sum_s V_s + 64 L * sum_s s * T_s
+__global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict__ seg, msm_plan p, u32 *__restrict__ win_out) {
+    u32 w = blockIdx.x, lane = threadIdx.x;
+    ge T = ge_identity(), V = ge_identity();
+    if (lane < p.S) {
+        u64 o = ((u64)w * p.S + lane) * 2;
+        T = ge_load(seg + 32 * o); V = ge_load(seg + 32 * (o + 1));
+    }
+    u32 log2m = 6; while ((1u << (log2m - 6)) < p.L) log2m++;      // 64 * L
+    ge total;
+    ge R = wave_weighted_sum(T, V, log2m, total);
+    if (lane == 0) ge_store(win_out + 32ull * w, R);
+}
+
+// Horner over the windows, most significant first; writes the compressed result and the identity flag
+__global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, msm_plan p, u32 *__restrict__ out_words /*8*/, u32 *__restrict__ out_flag,
+                                                   u32 *__restrict__ out_point /*32 words, may be null*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ge R = ge_load(win + 32ull * (p.W - 1));
+    for (int w = (int)p.W - 2; w >= 0; w--) {
+        for (u32 k = 0; k < p.c; k++) R = ge_double(R);
+        R = ge_add(R, ge_load(win + 32ull * w));
+    }
+    u32 enc[8]; ristretto_encode_words(enc, R);
+    for (int i = 0; i < 8; i++) out_words[i] = enc[i];
+    out_flag[0] = ge_ristretto_is_identity(R) ? 1u : 0u;
+    if (out_point) ge_store(out_point, R);
+}
+
+hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
+                      const msm_ws &ws, u32 *d_result, msm_mark_fn mark, void *mark_user) {
+#define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
+    u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
+    u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
+    hipError_t e;
+    MARK("msm_histogram");
+    if ((e = hipMemsetAsync(ws.hist, 0, n_buckets * 4, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws.big_list, 0, 4, st)) != hipSuccess) return e;
+    if (n) hipLaunchKernelGGL(k_msm_histogram, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.hist);
+    MARK("msm_scan");
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.hist, (u32)n_buckets, ws.offsets, ws.cursor);
+    MARK("msm_scatter");
+    if (n) hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.cursor, ws.sorted, sorted_cap);
+    MARK("msm_accumulate");
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, n, d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
+                       ws.buckets, ws.chunk_sums);
+    MARK("msm_merge");
+    hipLaunchKernelGGL(k_msm_merge, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.offsets, (u32)n_buckets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
+    hipLaunchKernelGGL(k_msm_merge_big, dim3(big_cap < 64 ? big_cap : 64), dim3(256), 0, st, ws.offsets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
+    MARK("msm_reduce");
+    hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets, p, ws.segs);
+    hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
+    MARK("msm_horner");
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins, p, d_result, d_result + 8, (u32 *)nullptr);
+#undef MARK
+    return hipGetLastError();
+}
+
+}  // namespace xhe

@@ -1,0 +1,63 @@
+// Host-callable launchers of the gfx950 kernels.  Each xhe_k_*.hip translation unit defines its kernels
+// and the launchers declared here; xhe_lib.hip only sequences them on the context's stream.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "xhe_verify_types.h"
+
+namespace xhe {
+
+struct msm_plan {
+    u32 c;        // window bits
+    u32 W;        // windows
+    u32 B;        // buckets per window = 2^(c-1)
+    u32 L;        // buckets per lane in the reduce stage
+    u32 S;        // segments per window = B / (64 L)   (<= 64)
+    u32 M;        // sorted entries per accumulate chunk
+};
+msm_plan msm_make_plan(u64 n);
+// device pointers of one multiscalar multiplication's workspace (sizes: see msm_workspace_bytes)
+struct msm_ws {
+    u32 *hist, *offsets, *cursor, *sorted, *buckets, *chunk_bucket, *chunk_sums, *big_list, *segs, *wins;
+};
+struct msm_ws_bytes { u64 hist, offsets, cursor, sorted, buckets, chunk_bucket, chunk_sums, big_list, segs, wins; };
+msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
+typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
+// result: 8 words of encoding at d_result[0..8), identity flag at d_result[8]
+hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
+                      const msm_ws &ws, u32 *d_result, msm_mark_fn mark, void *mark_user);
+
+// points
+void launch_decode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok);
+void launch_decode_niels(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok);
+void launch_encode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out);
+void launch_reduce_scalars(hipStream_t st, u32 *s, u64 n);
+void launch_count_bad(hipStream_t st, const u8 *ok, u64 n, u32 *out);
+void launch_base_points(hipStream_t st, u32 *out);
+void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pts);
+void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_windows, u32 *tab);
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, u32 n, u32 pt_base, u32 *pts, u8 *ok);
+void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
+void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp);
+// transcript, hashes, signatures
+void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, u32 *chal, u32 *tx_err, u32 *rp_err);
+void launch_blake3_preimages(hipStream_t st, const u8 *bytes, const dev_tx *txs, const u32 *hash_tx, u32 n, u8 *out);
+void launch_schnorr(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u8 *ok, const u32 *htab, const u8 *ms_hash, u32 *tx_err);
+// ledger scan
+static constexpr u32 SCAN_K = 4;          // operations per thread
+static constexpr u32 SCAN_BLOCK = 128;    // threads per block
+void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 *pts_in, const u32 *gtab, u32 *thread_excl, u32 *block_tot, const u32 *slot_last_op,
+                        u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok, u32 n_slots,
+                        u32 *final_cts);
+// proof scalars
+static constexpr u32 RPC_SCALARS = 53;    // Montgomery-limb scalars in a transaction's range-proof context
+void launch_sigma_cm(hipStream_t st, const u8 *bytes, const dev_cm *cms, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point, u32 *gh);
+void launch_sigma_xf(hipStream_t st, const u8 *bytes, const dev_xfer *xfers, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point,
+                     u32 *gh);
+void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out);
+void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *chal, const u32 *seed, u32 *scalars,
+                    u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err);
+void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 row0, u32 n_rows, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *mat);
+void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc);
+void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point);
+
+}  // namespace xhe

@@ -7,8 +7,9 @@
 #include <string>
 #include <vector>
 #include "../../include/xhe.h"
+#include <algorithm>
 #include "xhe_ingest.h"
-#include "xhe_verify.hip.h"
+#include "xhe_kernels.h"
 
 using namespace xhe;
 
@@ -56,7 +57,7 @@ struct stage_timer {
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
 };
 
-struct msm_workspace { dev_buf hist, offsets, cursor, sorted, buckets, segs, wins; };
+struct msm_workspace { dev_buf hist, offsets, cursor, sorted, buckets, chunk_bucket, chunk_sums, big_list, segs, wins; };
 
 struct xhe_ctx {
     int device = 0;
@@ -93,120 +94,27 @@ struct xhe_batch {
 
 static void set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) ctx->error = msg; else g_create_error = msg; }
 
-// ---------------------------------------------------------------------------------------------------
-namespace xhe {
-
-__global__ void __launch_bounds__(256, 2) k_decode_xyzt(const u32 *__restrict__ in, u64 n, u32 *__restrict__ out, u8 *__restrict__ ok) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = in[8 * i + k];
-    ge p; bool good = ristretto_decode_words(p, w);
-    ge_store(out + 32 * i, p);
-    ok[i] = good ? 1 : 0;
-}
-__global__ void __launch_bounds__(256, 2) k_decode_niels(const u32 *__restrict__ in, u64 n, u32 *__restrict__ out, u8 *__restrict__ ok) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = in[8 * i + k];
-    ge p; bool good = ristretto_decode_words(p, w);
-    ge_niels_store(out + 32 * i, ge_to_niels_affine(p));
-    ok[i] = good ? 1 : 0;
-}
-__global__ void __launch_bounds__(256, 2) k_encode_xyzt(const u32 *__restrict__ in, u64 n, u32 *__restrict__ out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ge p = ge_load(in + 32 * i);
-    u32 w[8]; ristretto_encode_words(w, p);
-#pragma unroll
-    for (int k = 0; k < 8; k++) out[8 * i + k] = w[k];
-}
-// 32-byte little-endian integers -> canonical scalars (value mod l), in place
-__global__ void __launch_bounds__(256) k_reduce_scalars(u32 *__restrict__ s, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = s[8 * i + k];
-    sc x = sc_from_words(w);
-    sc_to_words(w, x);
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[8 * i + k] = w[k];
-}
-__global__ void k_count_bad(const u8 *__restrict__ ok, u64 n, u32 *__restrict__ out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !ok[i]) atomicAdd(out, 1u);
-}
-
-// B = ristretto basepoint, H = from_uniform_bytes(SHA3-512(enc(B))) (src/elgamal.rs:16-24), as affine Niels
-__global__ void k_base_points(u32 *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const u8 bb[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
-                       0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
-    ge B; ristretto_decode(B, bb);
-    ge_niels_store(out, ge_to_niels_affine(B));
-    u8 h[64]; sha3_512(h, bb, 32);
-    ge H = ristretto_from_uniform_bytes(h);
-    ge_niels_store(out + 32, ge_to_niels_normalize(H));
-}
-// BulletproofGens (src/proofs.rs:20): thread per (party, G|H) walks its SHAKE256 stream, 64 generators
-__global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties, u32 cap, u32 *__restrict__ static_pts) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= 2 * n_parties) return;
-    u32 party = party0 + (g >> 1), which = g & 1;
-    sponge sp; sp.init(136, 0x1f);
-    const u8 tag[15] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n'};
-    sp.absorb(tag, 15);
-    u8 label[5] = {(u8)(which ? 'H' : 'G'), (u8)party, (u8)(party >> 8), (u8)(party >> 16), (u8)(party >> 24)};
-    sp.absorb(label, 5);
-    for (u32 i = 0; i < 64; i++) {
-        u8 ub[64]; sp.squeeze(ub, 64);
-        ge p = ristretto_from_uniform_bytes(ub);
-        u32 idx = 2 + (which ? cap : 0) + 64 * party + i;
-        ge_niels_store(static_pts + 32ull * idx, ge_to_niels_normalize(p));
-    }
-}
-
-}  // namespace xhe
-
-static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }
-
 // MSM over device-resident canonical scalars and affine-Niels records; result (8 words encoding, flag)
 // into d_result[0..8], d_result[8].
+static hipError_t timer_mark(void *user, const char *name) { xhe_ctx *ctx = (xhe_ctx *)user; return ctx->timer.mark(name, ctx->stream); }
+
 static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool timing) {
-    hipStream_t st = ctx->stream;
     msm_workspace &ws = ctx->msm;
     msm_plan p = msm_make_plan(n);
-    u64 n_buckets = (u64)p.W * p.B;
-    u64 sorted_cap = n * p.W;
-    if (sorted_cap == 0) sorted_cap = 1;
-    if (sorted_cap > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
-    HIPCHK(ctx, ws.hist.reserve(n_buckets * 4));
-    HIPCHK(ctx, ws.offsets.reserve((n_buckets + 1) * 4));
-    HIPCHK(ctx, ws.cursor.reserve(n_buckets * 4));
-    HIPCHK(ctx, ws.sorted.reserve(sorted_cap * 4));
-    HIPCHK(ctx, ws.buckets.reserve(n_buckets * 128));
-    HIPCHK(ctx, ws.segs.reserve((u64)p.W * p.S * 2 * 128));
-    HIPCHK(ctx, ws.wins.reserve((u64)p.W * 128));
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_histogram", st));
-    HIPCHK(ctx, hipMemsetAsync(ws.hist.p, 0, n_buckets * 4, st));
-    if (n) hipLaunchKernelGGL(k_msm_histogram, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.hist.as<u32>());
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_scan", st));
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.hist.as<u32>(), (u32)n_buckets, ws.offsets.as<u32>(), ws.cursor.as<u32>());
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_scatter", st));
-    if (n) hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.cursor.as<u32>(), ws.sorted.as<u32>(), sorted_cap);
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_accumulate", st));
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, d_niels, n, d_term_point, n_points, ws.offsets.as<u32>(),
-                       ws.sorted.as<u32>(), (u32)n_buckets, ws.buckets.as<u32>());
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_reduce", st));
-    hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets.as<u32>(), p, ws.segs.as<u32>());
-    hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs.as<u32>(), p, ws.wins.as<u32>());
-    if (timing) HIPCHK(ctx, ctx->timer.mark("msm_horner", st));
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins.as<u32>(), p, d_result, d_result + 8, (u32 *)nullptr);
-    HIPCHK(ctx, hipGetLastError());
+    if (n * p.W > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
+    msm_ws_bytes need = msm_workspace_bytes(n, p);
+    HIPCHK(ctx, ws.hist.reserve(need.hist));
+    HIPCHK(ctx, ws.offsets.reserve(need.offsets));
+    HIPCHK(ctx, ws.cursor.reserve(need.cursor));
+    HIPCHK(ctx, ws.sorted.reserve(need.sorted));
+    HIPCHK(ctx, ws.buckets.reserve(need.buckets));
+    HIPCHK(ctx, ws.chunk_sums.reserve(need.chunk_sums));
+    HIPCHK(ctx, ws.big_list.reserve(need.big_list));
+    HIPCHK(ctx, ws.segs.reserve(need.segs));
+    HIPCHK(ctx, ws.wins.reserve(need.wins));
+    msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.cursor.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), nullptr, ws.chunk_sums.as<u32>(),
+             ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
+    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, timing ? timer_mark : nullptr, ctx));
     return 0;
 }
 
@@ -217,9 +125,9 @@ static int32_t ensure_tables(xhe_ctx *ctx, u32 cap) {
         HIPCHK(ctx, ctx->base_pts.reserve(2 * 128));
         HIPCHK(ctx, ctx->gtab.reserve(8 * 256 * 128));
         HIPCHK(ctx, ctx->htab.reserve(32 * 256 * 128));
-        hipLaunchKernelGGL(k_base_points, dim3(1), dim3(64), 0, st, ctx->base_pts.as<u32>());
-        hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for(8 * 256, 256)), dim3(256), 0, st, ctx->base_pts.as<u32>(), 8u, ctx->gtab.as<u32>());
-        hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for(32 * 256, 256)), dim3(256), 0, st, ctx->base_pts.as<u32>() + 32, 32u, ctx->htab.as<u32>());
+        launch_base_points(st, ctx->base_pts.as<u32>());
+        launch_build_fixed_table(st, ctx->base_pts.as<u32>(), 8u, ctx->gtab.as<u32>());
+        launch_build_fixed_table(st, ctx->base_pts.as<u32>() + 32, 32u, ctx->htab.as<u32>());
         HIPCHK(ctx, hipGetLastError());
         ctx->tables_ready = true;
     }
@@ -228,7 +136,7 @@ static int32_t ensure_tables(xhe_ctx *ctx, u32 cap) {
         HIPCHK(ctx, fresh.reserve((2ull + 2ull * cap) * 128));
         HIPCHK(ctx, hipMemcpyAsync(fresh.p, ctx->base_pts.p, 256, hipMemcpyDeviceToDevice, st));
         // generators are regenerated for the new layout (one-off per capacity growth)
-        hipLaunchKernelGGL(k_bp_generators, dim3(grid_for(2 * (cap / 64), 64)), dim3(64), 0, st, 0u, cap / 64, cap, fresh.as<u32>());
+        launch_bp_generators(st, cap / 64, cap, fresh.as<u32>());
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(st));
         ctx->static_pts.release();
@@ -270,7 +178,7 @@ void xhe_destroy(xhe_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.cursor,
-                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts})
+                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts})
         b->release();
     ctx->timer.release();
     (void)hipStreamDestroy(ctx->stream);
@@ -294,7 +202,7 @@ int32_t xhe_ristretto_decompress_batch(xhe_ctx *ctx, uint64_t n, const uint8_t *
     HIPCHK(ctx, ctx->xyzt.reserve(n * 128));
     HIPCHK(ctx, ctx->ok.reserve(n));
     HIPCHK(ctx, hipMemcpyAsync(ctx->in_bytes.p, in32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_decode_xyzt, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->in_bytes.as<u32>(), n, ctx->xyzt.as<u32>(), ctx->ok.as<u8>());
+    launch_decode_xyzt(ctx->stream, ctx->in_bytes.as<u32>(), n, ctx->xyzt.as<u32>(), ctx->ok.as<u8>());
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_xyzt128, ctx->xyzt.p, n * 128, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ok, ctx->ok.p, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -309,7 +217,7 @@ int32_t xhe_ristretto_compress_batch(xhe_ctx *ctx, uint64_t n, const uint8_t *in
     HIPCHK(ctx, ctx->xyzt.reserve(n * 128));
     HIPCHK(ctx, ctx->in_bytes.reserve(n * 32));
     HIPCHK(ctx, hipMemcpyAsync(ctx->xyzt.p, in_xyzt128, n * 128, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_encode_xyzt, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->xyzt.as<u32>(), n, ctx->in_bytes.as<u32>());
+    launch_encode_xyzt(ctx->stream, ctx->xyzt.as<u32>(), n, ctx->in_bytes.as<u32>());
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out32, ctx->in_bytes.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -333,9 +241,9 @@ int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, cons
     if (n) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->in_bytes.p, points32, n * 32, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(ctx->scalars.p, scalars32, n * 32, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_decode_niels, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->in_bytes.as<u32>(), n, ctx->niels.as<u32>(), ctx->ok.as<u8>());
-        hipLaunchKernelGGL(k_count_bad, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->ok.as<u8>(), n, ctx->result.as<u32>() + 12);
-        hipLaunchKernelGGL(k_reduce_scalars, dim3(grid_for(n, 256)), dim3(256), 0, st, ctx->scalars.as<u32>(), n);
+        launch_decode_niels(st, ctx->in_bytes.as<u32>(), n, ctx->niels.as<u32>(), ctx->ok.as<u8>());
+        launch_count_bad(st, ctx->ok.as<u8>(), n, ctx->result.as<u32>() + 12);
+        launch_reduce_scalars(st, ctx->scalars.as<u32>(), n);
     }
     int32_t rc = msm_device(ctx, ctx->scalars.as<u32>(), ctx->niels.as<u32>(), nullptr, n, n, ctx->result.as<u32>(), true);
     if (rc) return rc;
@@ -493,34 +401,21 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     const u32 *sd = B->seed.as<u32>();
 
     HIPCHK(ctx, tm.mark("decode", st));
-    if (n_dec) hipLaunchKernelGGL(k_decode_list, dim3(grid_for(n_dec, 256)), dim3(256), 0, st, bytes, B->decs.as<dev_dec>(), n_dec, hb.n_static, pts, ok);
+    launch_decode_list(st, bytes, B->decs.as<dev_dec>(), n_dec, hb.n_static, pts, ok);
     HIPCHK(ctx, tm.mark("transcript", st));
-    hipLaunchKernelGGL(k_transcript, dim3(grid_for(n_txs, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, n_txs, chal, tx_err, rp_err);
+    launch_transcript(st, bytes, txs, cms, xfers, n_txs, chal, tx_err, rp_err);
     HIPCHK(ctx, tm.mark("ledger_scan", st));
-    if (n_ops) {
-        u32 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
-        hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(),
-                           B->block_tot.as<u32>());
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, B->block_tot.as<u32>(), scan_blocks);
-        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(),
-                           B->block_tot.as<u32>(), B->slot_last_op.as<u32>(), B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>());
-        if (n_cm) hipLaunchKernelGGL(k_scan_emit, dim3(grid_for(2 * n_cm, 256)), dim3(256), 0, st, B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), B->slot_base.as<u32>(),
-                                     n_cm, hb.emit_base, pts, ok);
-        if (n_slots) hipLaunchKernelGGL(k_scan_final, dim3(grid_for(2 * n_slots, 256)), dim3(256), 0, st, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots,
-                                        B->final_cts.as<u32>());
-    }
+    launch_ledger_scan(st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
+                       B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok, n_slots,
+                       B->final_cts.as<u32>());
     HIPCHK(ctx, tm.mark("signatures", st));
-    if (!hb.ms_hash_tx.empty())
-        hipLaunchKernelGGL(k_blake3_preimages, dim3(grid_for(hb.ms_hash_tx.size(), 64)), dim3(64), 0, st, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(),
-                           B->ms_hash.as<u8>());
-    if (n_sigs) hipLaunchKernelGGL(k_schnorr, dim3(grid_for(n_sigs, 64)), dim3(64), 0, st, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(),
-                                   B->ms_hash.as<u8>(), tx_err);
+    launch_blake3_preimages(st, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
+    launch_schnorr(st, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(), B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.mark("sigma_scalars", st));
-    if (n_cm) hipLaunchKernelGGL(k_sigma_cm, dim3(grid_for(n_cm, 256)), dim3(256), 0, st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
-    if (n_xf) hipLaunchKernelGGL(k_sigma_xf, dim3(grid_for(n_xf, 256)), dim3(256), 0, st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
+    launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
+    launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
     HIPCHK(ctx, tm.mark("rangeproof_scalars", st));
-    hipLaunchKernelGGL(k_rp_prep, dim3(grid_for(n_txs, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(),
-                       gh + 18ull * (n_cm + n_xf), rp_err);
+    launch_rp_prep(st, bytes, txs, cms, xfers, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh + 18ull * (n_cm + n_xf), rp_err);
     for (u32 lg = 6; lg < 16; lg++) {
         u32 rows = (u32)hb.lg_groups[lg].size();
         if (!rows) continue;
@@ -528,23 +423,21 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         u32 tile_rows = (u32)std::min<u64>(rows, std::max<u64>(1, (1ull << 30) / row_bytes));
         for (u32 r0 = 0; r0 < rows; r0 += tile_rows) {
             u32 nr = std::min(tile_rows, rows - r0);
-            hipLaunchKernelGGL(k_rp_matrix, dim3(grid_for((u64)nr << lg, 256)), dim3(256), 0, st, B->group_txs.as<u32>() + B->group_off[lg], r0, nr, lg,
-                               B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
-            hipLaunchKernelGGL(k_rp_colsum, dim3(grid_for(2ull << lg, 256)), dim3(256), 0, st, B->rp_mat.as<u32>(), nr, lg, hb.nm_cap, B->rp_acc.as<u32>());
+            launch_rp_matrix(st, B->group_txs.as<u32>() + B->group_off[lg], r0, nr, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
+            launch_rp_colsum(st, B->rp_mat.as<u32>(), nr, lg, hb.nm_cap, B->rp_acc.as<u32>());
         }
     }
-    u32 sum_blocks = std::min<u32>(128, grid_for(n_parts, 256));
-    hipLaunchKernelGGL(k_sc_sum_partial, dim3(sum_blocks), dim3(256), 0, st, gh, n_parts, 2u, B->gh_sums.as<u32>());
-    hipLaunchKernelGGL(k_static_terms, dim3(grid_for(hb.n_static, 256)), dim3(256), 0, st, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap,
-                       hb.static_term_off, scalars, term_point);
+    u32 sum_blocks = std::min<u32>(128, (n_parts + 255) / 256);
+    launch_sc_sum_partial(st, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
+    launch_static_terms(st, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap, hb.static_term_off, scalars, term_point);
     HIPCHK(ctx, tm.mark("point_errors", st));
-    hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
+    launch_point_errors(st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipGetLastError());
     // merged multiscalar check: sigma terms + range-proof terms + static generators
     int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, true);
     if (rc) return rc;
     HIPCHK(ctx, tm.mark("verdict", st));
-    hipLaunchKernelGGL(k_verdict, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
+    launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
     HIPCHK(ctx, tm.mark("end", st));
     u32 host[16];
     HIPCHK(ctx, hipMemcpyAsync(host, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
@@ -562,10 +455,10 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         HIPCHK(ctx, s2.reserve(32ull * (n_sig_terms + 2))); HIPCHK(ctx, tp2.reserve(4ull * (n_sig_terms + 2))); HIPCHK(ctx, r2.reserve(64));
         HIPCHK(ctx, hipMemcpyAsync(s2.p, scalars, 32ull * n_sig_terms, hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(tp2.p, term_point, 4ull * n_sig_terms, hipMemcpyDeviceToDevice, st));
-        u32 sb = std::min<u32>(128, std::max<u32>(1, grid_for(n_cm + n_xf, 256)));
-        hipLaunchKernelGGL(k_sc_sum_partial, dim3(sb), dim3(256), 0, st, gh, n_cm + n_xf, 2u, B->gh_sums.as<u32>());
+        u32 sb = std::min<u32>(128, std::max<u32>(1, (n_cm + n_xf + 255) / 256));
+        launch_sc_sum_partial(st, sb, gh, n_cm + n_xf, 2u, B->gh_sums.as<u32>());
         // reuse k_static_terms with nm_cap = 0: writes only the B and H scalars
-        hipLaunchKernelGGL(k_static_terms, dim3(1), dim3(256), 0, st, B->gh_sums.as<u32>(), sb, B->rp_acc.as<u32>(), 0u, n_sig_terms, s2.as<u32>(), tp2.as<u32>());
+        launch_static_terms(st, B->gh_sums.as<u32>(), sb, B->rp_acc.as<u32>(), 0u, n_sig_terms, s2.as<u32>(), tp2.as<u32>());
         HIPCHK(ctx, hipMemsetAsync(r2.p, 0, 64, st));
         rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false);
         u32 h2[16];
