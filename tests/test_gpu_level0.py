@@ -58,8 +58,30 @@ def test_msm_parity(engine, oracle, n):
     r = rng(1000 + n)
     pool = _oracle_points(oracle, r, min(max(n, 1), 64))
     pts = b"".join(pool[i % len(pool)] for i in range(n))
-    kinds = [0, 1, S.L - 1, 2**252, S.L, 2**256 - 1]
+    kinds = [0, 1, S.L - 1, 2**252, S.L, 2**256 - 1, (S.L - 1) // 2, (S.L + 1) // 2, (S.L - 3) // 2, 2**251, 2**251 - 1, S.L - 2**251]
     scal = b"".join(le32(kinds[i % len(kinds)] if i % 17 == 0 else r.randrange(S.L)) for i in range(n))
+    got, ident = engine.msm_vartime(scal, pts)
+    o, idf = buf(32), buf(1)
+    assert oracle.xo_msm_vartime(n, scal, pts, o, idf) == 0
+    assert got == bytes(o)
+    assert ident == bool(idf[0])
+
+
+@pytest.mark.parametrize("n,kind", [(3000, "equal"), (3000, "two"), (20000, "small"), (70000, "equal")])
+def test_msm_skewed_digits(engine, oracle, n, kind):
+    """Digit distributions that put most terms into a handful of buckets (buckets spanning many chunks)."""
+    r = rng(5000 + n)
+    pool = _oracle_points(oracle, r, 32)
+    pts = b"".join(pool[r.randrange(32)] for _ in range(n))
+    if kind == "equal":
+        k = r.randrange(S.L)
+        vals = [k] * n
+    elif kind == "two":
+        a, b = r.randrange(S.L), r.randrange(S.L)
+        vals = [a if r.random() < 0.9 else b for _ in range(n)]
+    else:
+        vals = [r.randrange(4) for _ in range(n)]
+    scal = b"".join(le32(v) for v in vals)
     got, ident = engine.msm_vartime(scal, pts)
     o, idf = buf(32), buf(1)
     assert oracle.xo_msm_vartime(n, scal, pts, o, idf) == 0

@@ -26,16 +26,15 @@ namespace xhe {
 // window width by term count: balances n*W bucket additions against 2*W*B reduction additions and
 // keeps W*B large enough to occupy the 256 CUs
 msm_plan msm_make_plan(u64 n) {
-    u32 c;
+    u32 c;                                           // widths dividing 252 leave no narrow top window
     if (n < 256) c = 7;
-    else if (n < 4096) c = 8;
-    else if (n < 32768) c = 10;
+    else if (n < 4096) c = 9;
     else if (n < 200000) c = 12;
     else if (n < 1500000) c = 14;
     else if (n < 6000000) c = 15;
     else c = 16;
     msm_plan p;
-    p.c = c; p.W = 253 / c + 1; p.B = 1u << (c - 1);
+    p.c = c; p.W = (252 + c - 1) / c; p.B = 1u << (c - 1);          // recoded scalars are below 2^252
     u32 L = p.B / 4096; if (L < 1) L = 1;          // S = B/(64L) <= 64
     if (p.B < 64) L = 1;
     p.L = L; p.S = (p.B + 64 * L - 1) / (64 * L);
@@ -59,9 +58,28 @@ msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
 }
 
 // thread per term: signed radix-2^c digits of a canonical scalar (eight words), each in
-// [-(2^(c-1)-1), 2^(c-1)], serial carry from the least significant window
+// [-2^(c-1), 2^(c-1)], serial carry from the least significant window.  A scalar above (l-1)/2 is
+// replaced by l - s with every digit's sign flipped: the recoded value is below 2^251 + 2^124, so
+// ceil(252/c) windows hold it with no carry out of the top one, and the digits of the top window are as
+// evenly spread as those of the others (without this, half of all terms would share one carry bucket).
 template <typename F>
-__device__ __forceinline__ void msm_for_each_digit(const u32 s[8], u32 c, u32 W, F f) {
+__device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32 W, F f) {
+    const u32 LW[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};          // l
+    const u32 HW[8] = {0x2e7ae9f6u, 0x2c09318du, 0x517bce6bu, 0x0a6f7cefu, 0u, 0u, 0u, 0x08000000u};          // (l-1)/2
+    bool flip = false, decided = false;
+#pragma unroll
+    for (int k = 7; k >= 0; k--)
+        if (!decided && s_in[k] != HW[k]) { flip = s_in[k] > HW[k]; decided = true; }
+    u32 s[8];
+    {
+        u64 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u64 dlt = (u64)LW[k] - s_in[k] - borrow;
+            s[k] = flip ? (u32)dlt : s_in[k];
+            borrow = (dlt >> 32) & 1;
+        }
+    }
     u32 carry = 0;
     const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
     for (u32 w = 0; w < W; w++) {
@@ -74,7 +92,7 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s[8], u32 c, u32 W,
         u32 v = raw + carry;
         int d;
         if (v > half) { d = (int)v - (int)(1u << c); carry = 1; } else { d = (int)v; carry = 0; }
-        f(w, d);
+        f(w, flip ? -d : d);
     }
 }
 

@@ -183,30 +183,39 @@ __global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, co
     }
 }
 
-// thread per (row, i): the scalars of G_i and H_i contributed by one transaction of the lg-group
-__global__ void __launch_bounds__(256, 2) k_rp_matrix(const u32 *__restrict__ group_txs, u32 row0, u32 n_rows, u32 lg, const u32 *__restrict__ rp_ctx,
-                                                      const u32 *__restrict__ rp_err, u32 *__restrict__ mat) {
+// thread per (tile of rows_per_thread transactions of the lg-group, i): partial column sums of the scalars
+// of G_i and H_i, written as row `tile` of part[tiles][2 * 2^lg]
+__global__ void __launch_bounds__(256, 2) k_rp_matrix(const u32 *__restrict__ group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *__restrict__ rp_ctx,
+                                                      const u32 *__restrict__ rp_err, u32 *__restrict__ part) {
     u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 nm = 1u << lg;
-    if (g >= (u64)n_rows * nm) return;
-    u32 r = (u32)(g >> lg), idx = (u32)g & (nm - 1);
-    u32 tx = group_txs[row0 + r];
-    u32 *out_g = mat + 9ull * ((u64)r * 2 * nm + idx), *out_h = mat + 9ull * ((u64)r * 2 * nm + nm + idx);
-    if (rp_err[tx]) { store_sc_limbs(out_g, sc_zero()); store_sc_limbs(out_h, sc_zero()); return; }
-    const u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * tx;
-    sc sprod = load_sc_limbs(ctx + 9 * RPC_COEF_G), tprod = load_sc_limbs(ctx + 9 * RPC_COEF_H3), eprod = load_sc_limbs(ctx + 9 * RPC_COEF_H2);
-    for (u32 b = 0; b < lg; b++) {
-        sc u2 = load_sc_limbs(ctx + 9 * (RPC_U2 + b));
-        if ((idx >> b) & 1) {
-            sprod = sc_mul(sprod, u2);
-            tprod = sc_mul(tprod, load_sc_limbs(ctx + 9 * (RPC_Y2INV + b)));
-            eprod = sc_mul(eprod, load_sc_limbs(ctx + 9 * ((b < 6) ? (RPC_E + b) : (RPC_F + b - 6))));
-        } else {
-            tprod = sc_mul(tprod, u2);
+    u32 tile = (u32)(g >> lg), idx = (u32)g & (nm - 1);
+    u64 r0 = (u64)tile * rows_per_thread;
+    if (r0 >= n_rows) return;
+    u32 r1 = (u32)((r0 + rows_per_thread < n_rows) ? r0 + rows_per_thread : n_rows);
+    sc sum_g = sc_zero(), sum_h = sc_zero();
+    u32 pending = 0;
+    for (u32 r = (u32)r0; r < r1; r++) {
+        u32 tx = group_txs[r];
+        if (rp_err[tx]) continue;
+        const u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * tx;
+        sc sprod = load_sc_limbs(ctx + 9 * RPC_COEF_G), tprod = load_sc_limbs(ctx + 9 * RPC_COEF_H3), eprod = load_sc_limbs(ctx + 9 * RPC_COEF_H2);
+        for (u32 b = 0; b < lg; b++) {
+            sc u2 = load_sc_limbs(ctx + 9 * (RPC_U2 + b));
+            if ((idx >> b) & 1) {
+                sprod = sc_mul(sprod, u2);
+                tprod = sc_mul(tprod, load_sc_limbs(ctx + 9 * (RPC_Y2INV + b)));
+                eprod = sc_mul(eprod, load_sc_limbs(ctx + 9 * ((b < 6) ? (RPC_E + b) : (RPC_F + b - 6))));
+            } else {
+                tprod = sc_mul(tprod, u2);
+            }
         }
+        sum_g = sc_add(sum_g, sc_add(load_sc_limbs(ctx + 9 * RPC_NEG_RHO_Z), sprod));
+        sum_h = sc_add(sum_h, sc_norm(sc_add_lazy(sc_add(load_sc_limbs(ctx + 9 * RPC_RHO_Z), eprod), tprod)));
+        if (++pending == 8) { sum_g = sc_reduce_mont(sum_g); sum_h = sc_reduce_mont(sum_h); pending = 0; }
     }
-    store_sc_limbs(out_g, sc_add(load_sc_limbs(ctx + 9 * RPC_NEG_RHO_Z), sprod));
-    store_sc_limbs(out_h, sc_norm(sc_add_lazy(sc_add(load_sc_limbs(ctx + 9 * RPC_RHO_Z), eprod), tprod)));
+    store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + idx), sc_reduce_mont(sum_g));
+    store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + nm + idx), sc_reduce_mont(sum_h));
 }
 // thread per column: acc[col] += sum over rows
 __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *__restrict__ acc /* 2*nm_cap scalars */) {
@@ -250,8 +259,10 @@ void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const de
                     u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_rp_prep, dim3(grid_for(n_txs, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, n_txs, chal, seed, scalars, term_point, rp_ctx, gh, rp_err);
 }
-void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 row0, u32 n_rows, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *mat) {
-    if (n_rows) hipLaunchKernelGGL(k_rp_matrix, dim3(grid_for((u64)n_rows << lg, 256)), dim3(256), 0, st, group_txs, row0, n_rows, lg, rp_ctx, rp_err, mat);
+void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part) {
+    if (!n_rows || !rows_per_thread) return;
+    u64 tiles = ((u64)n_rows + rows_per_thread - 1) / rows_per_thread;
+    hipLaunchKernelGGL(k_rp_matrix, dim3(grid_for(tiles << lg, 256)), dim3(256), 0, st, group_txs, n_rows, rows_per_thread, lg, rp_ctx, rp_err, part);
 }
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc) {
     hipLaunchKernelGGL(k_rp_colsum, dim3(grid_for(2ull << lg, 256)), dim3(256), 0, st, mat, n_rows, lg, nm_cap, acc);

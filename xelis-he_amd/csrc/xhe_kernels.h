@@ -56,7 +56,9 @@ void launch_sigma_xf(hipStream_t st, const u8 *bytes, const dev_xfer *xfers, con
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out);
 void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *chal, const u32 *seed, u32 *scalars,
                     u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err);
-void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 row0, u32 n_rows, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *mat);
+// rows_per_thread transactions per thread: part[ceil(n_rows / rows_per_thread)][2 * 2^lg] partial column sums, summed by launch_rp_colsum
+static inline u32 rp_rows_per_thread(u64 n_rows, u32 lg) { u64 r = (n_rows << lg) >> 17; return r < 1 ? 1u : r > 64 ? 64u : (u32)r; }
+void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part);
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc);
 void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point);
 

@@ -303,14 +303,13 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
     RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32);
-    // the range-proof scalar matrix is tiled: at most ~1 GiB at a time
+    // partial column sums of the range-proof scalar matrix: one row per tile of transactions
     {
         u64 worst = 0;
         for (u32 lg = 6; lg < 16; lg++) {
             u64 rows = hb.lg_groups[lg].size(); if (!rows) continue;
-            u64 row_bytes = 72ull << lg;
-            u64 tile_rows = std::min<u64>(rows, std::max<u64>(1, (1ull << 30) / row_bytes));
-            worst = std::max(worst, tile_rows * row_bytes);
+            u32 rpt = rp_rows_per_thread(rows, lg);
+            worst = std::max<u64>(worst, ((rows + rpt - 1) / rpt) * (72ull << lg));
         }
         RS(rp_mat, worst);
     }
@@ -419,13 +418,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     for (u32 lg = 6; lg < 16; lg++) {
         u32 rows = (u32)hb.lg_groups[lg].size();
         if (!rows) continue;
-        u64 row_bytes = 72ull << lg;
-        u32 tile_rows = (u32)std::min<u64>(rows, std::max<u64>(1, (1ull << 30) / row_bytes));
-        for (u32 r0 = 0; r0 < rows; r0 += tile_rows) {
-            u32 nr = std::min(tile_rows, rows - r0);
-            launch_rp_matrix(st, B->group_txs.as<u32>() + B->group_off[lg], r0, nr, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
-            launch_rp_colsum(st, B->rp_mat.as<u32>(), nr, lg, hb.nm_cap, B->rp_acc.as<u32>());
-        }
+        u32 rpt = rp_rows_per_thread(rows, lg), tiles = (rows + rpt - 1) / rpt;
+        launch_rp_matrix(st, B->group_txs.as<u32>() + B->group_off[lg], rows, rpt, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
+        launch_rp_colsum(st, B->rp_mat.as<u32>(), tiles, lg, hb.nm_cap, B->rp_acc.as<u32>());
     }
     u32 sum_blocks = std::min<u32>(128, (n_parts + 255) / 256);
     launch_sc_sum_partial(st, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
