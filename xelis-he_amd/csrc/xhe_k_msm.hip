@@ -43,6 +43,7 @@ msm_plan msm_make_plan(u64 n) {
     return p;
 }
 
+static constexpr u32 SCAN_TILE = 1024;       // counters per workgroup of the bucket-offset scan
 static constexpr u32 MERGE_SPAN_MAX = 8;     // a bucket cut into more chunks than this is reduced by a workgroup
 
 static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return (e + p.M - 1) / p.M + 1; }
@@ -53,7 +54,7 @@ msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
     b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.cursor = nb * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
     b.chunk_bucket = 64;                       // unused slot kept for layout stability
     b.chunk_sums = chunks * 2 * 128; b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
-    b.segs = (u64)p.W * p.S * 2 * 128; b.wins = (u64)p.W * 128;
+    b.segs = (u64)p.W * p.S * 2 * 128 + (nb / SCAN_TILE + 1) * 4; b.wins = (u64)p.W * 128;          // segs doubles as the scan's tile sums
     return b;
 }
 
@@ -107,25 +108,53 @@ __global__ void __launch_bounds__(256) k_msm_histogram(const u32 *__restrict__ s
     });
 }
 
-// single workgroup exclusive scan of `count` counters into offsets[count + 1]; cursor = copy of offsets
-__global__ void __launch_bounds__(1024) k_msm_scan(const u32 *__restrict__ hist, u32 count, u32 *__restrict__ offsets, u32 *__restrict__ cursor) {
-    __shared__ u32 part[1024];
+// Exclusive scan of `count` counters into offsets[count + 1] (cursor = copy of offsets), two launches:
+// sums of 1024-counter tiles, then every tile adds the sums of the tiles before it to its local scan.
+__device__ __forceinline__ u32 block_sum_256(u32 v, u32 *lds /* 4 */) {
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32 *__restrict__ hist, u32 count, u32 *__restrict__ tile_sums) {
+    __shared__ u32 lds[4];
+    u32 i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    u32 v = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) if (i0 + k < count) v += hist[i0 + k];
+    u32 r = block_sum_256(v, lds);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, u32 count, const u32 *__restrict__ tile_sums, u32 *__restrict__ offsets,
+                                                  u32 *__restrict__ cursor) {
+    __shared__ u32 lds[4];
+    __shared__ u32 part[256];
     u32 t = threadIdx.x;
-    u32 per = (count + 1023) / 1024;
-    u32 lo = t * per, hi = lo + per; if (hi > count) hi = count; if (lo > count) lo = count;
-    u32 sum = 0;
-    for (u32 i = lo; i < hi; i++) sum += hist[i];
+    u32 before = 0;
+    for (u32 j = t; j < blockIdx.x; j += 256) before += tile_sums[j];
+    u32 base = block_sum_256(before, lds);
+    u32 i0 = blockIdx.x * SCAN_TILE + 4 * t;
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) { v[k] = (i0 + k < count) ? hist[i0 + k] : 0; sum += v[k]; }
     part[t] = sum;
     __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
-        u32 v = (t >= d) ? part[t - d] : 0;
+    for (u32 d = 1; d < 256; d <<= 1) {           // Hillis-Steele inclusive scan
+        u32 o = (t >= d) ? part[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += o;
         __syncthreads();
     }
-    u32 run = (t == 0) ? 0 : part[t - 1];
-    for (u32 i = lo; i < hi; i++) { offsets[i] = run; cursor[i] = run; run += hist[i]; }
-    if (t == 1023) offsets[count] = part[1023];
+    u32 run = base + part[t] - sum;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        if (i0 + k < count) { offsets[i0 + k] = run; cursor[i0 + k] = run; }
+        run += v[k];
+        if (i0 + k + 1 == count) offsets[count] = run;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_msm_scatter(const u32 *__restrict__ scalars, u64 n, msm_plan p, u32 *__restrict__ cursor,
@@ -341,7 +370,9 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     if ((e = hipMemsetAsync(ws.big_list, 0, 4, st)) != hipSuccess) return e;
     if (n) hipLaunchKernelGGL(k_msm_histogram, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.hist);
     MARK("msm_scan");
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.hist, (u32)n_buckets, ws.offsets, ws.cursor);
+    u32 tiles = (u32)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
+    hipLaunchKernelGGL(k_msm_scan, dim3(tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets, ws.cursor);
     MARK("msm_scatter");
     if (n) hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.cursor, ws.sorted, sorted_cap);
     MARK("msm_accumulate");

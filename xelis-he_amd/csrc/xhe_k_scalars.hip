@@ -217,18 +217,26 @@ __global__ void __launch_bounds__(256, 2) k_rp_matrix(const u32 *__restrict__ gr
     store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + idx), sc_reduce_mont(sum_g));
     store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + nm + idx), sc_reduce_mont(sum_h));
 }
-// thread per column: acc[col] += sum over rows
+// workgroup per column: acc[col] += sum over the rows of part[n_rows][2 * 2^lg]
 __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *__restrict__ acc /* 2*nm_cap scalars */) {
-    u32 col = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u32 lds[256 * 9];
+    u32 col = blockIdx.x, t = threadIdx.x;
     u32 nm = 1u << lg;
     if (col >= 2 * nm) return;
     u32 dst = col < nm ? col : nm_cap + (col - nm);
-    sc a = load_sc_limbs(acc + 9ull * dst); u32 cnt = 0;
-    for (u32 r = 0; r < n_rows; r++) {
+    sc a = sc_zero(); u32 cnt = 0;
+    for (u32 r = t; r < n_rows; r += 256) {
         a = sc_add(a, load_sc_limbs(mat + 9ull * ((u64)r * 2 * nm + col)));
         if (++cnt == 16) { a = sc_reduce_mont(a); cnt = 0; }
     }
-    store_sc_limbs(acc + 9ull * dst, sc_norm(sc_reduce_mont(a)));
+    a = sc_reduce_mont(a);
+    for (u32 d = 128; d >= 1; d >>= 1) {
+        store_sc_limbs(lds + 9 * t, a);
+        __syncthreads();
+        if (t < d) a = sc_reduce_mont(sc_add(a, load_sc_limbs(lds + 9 * (t + d))));
+        __syncthreads();
+    }
+    if (t == 0) store_sc_limbs(acc + 9ull * dst, sc_norm(sc_reduce_mont(sc_add(a, load_sc_limbs(acc + 9ull * dst)))));
 }
 // static terms: scalars of B, H (sums of the per-proof parts) and of G_i, H_i (column sums)
 __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh_sums /* n_parts x 2 */, u32 n_parts, const u32 *__restrict__ acc, u32 nm_cap,
@@ -265,7 +273,7 @@ void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows
     hipLaunchKernelGGL(k_rp_matrix, dim3(grid_for(tiles << lg, 256)), dim3(256), 0, st, group_txs, n_rows, rows_per_thread, lg, rp_ctx, rp_err, part);
 }
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc) {
-    hipLaunchKernelGGL(k_rp_colsum, dim3(grid_for(2ull << lg, 256)), dim3(256), 0, st, mat, n_rows, lg, nm_cap, acc);
+    hipLaunchKernelGGL(k_rp_colsum, dim3(2u << lg), dim3(256), 0, st, mat, n_rows, lg, nm_cap, acc);
 }
 void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point) {
     hipLaunchKernelGGL(k_static_terms, dim3(grid_for(2 + 2 * nm_cap, 256)), dim3(256), 0, st, gh_sums, n_parts, acc, nm_cap, static_term_off, scalars, term_point);

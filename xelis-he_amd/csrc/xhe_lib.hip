@@ -35,23 +35,47 @@ struct dev_buf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// Stage times from HIP events.  mark() opens a stage on the main stream that lasts until the next mark();
+// open()/close() bracket a stage on any stream (stages on different streams overlap in time).
 struct stage_timer {
+    struct span { const char *name; hipEvent_t a, b; };
     std::vector<std::pair<const char *, hipEvent_t>> marks;
+    std::vector<span> spans;
     std::vector<hipEvent_t> pool; size_t used = 0;
     std::vector<const char *> names; std::vector<float> ms;
-    void begin() { used = 0; marks.clear(); }
-    hipError_t mark(const char *name, hipStream_t s) {
+    void begin() { used = 0; marks.clear(); spans.clear(); }
+    hipError_t take(hipEvent_t *out) {
         if (used == pool.size()) { hipEvent_t e; hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; pool.push_back(e); }
-        hipEvent_t e = pool[used++];
+        *out = pool[used++];
+        return hipSuccess;
+    }
+    hipError_t mark(const char *name, hipStream_t s) {
+        hipEvent_t e; hipError_t r = take(&e); if (r != hipSuccess) return r;
         marks.push_back({name, e});
         return hipEventRecord(e, s);
     }
-    // after the stream is synchronised: stage i spans mark i -> mark i+1 and carries mark i's name
+    hipError_t open(const char *name, hipStream_t s) {
+        span sp{name, nullptr, nullptr};
+        hipError_t r = take(&sp.a); if (r != hipSuccess) return r;
+        r = take(&sp.b); if (r != hipSuccess) return r;
+        spans.push_back(sp);
+        return hipEventRecord(sp.a, s);
+    }
+    hipError_t close(hipStream_t s) { return hipEventRecord(spans.back().b, s); }
+    // after every stream is synchronised
     void finish() {
         names.clear(); ms.clear();
         for (size_t i = 0; i + 1 < marks.size(); i++) {
             float t = 0; if (hipEventElapsedTime(&t, marks[i].second, marks[i + 1].second) != hipSuccess) t = -1;
             names.push_back(marks[i].first); ms.push_back(t);
+        }
+        for (auto &sp : spans) {
+            float t = 0; if (hipEventElapsedTime(&t, sp.a, sp.b) != hipSuccess) t = -1;
+            names.push_back(sp.name); ms.push_back(t);
+        }
+        if (marks.size() >= 2) {
+            float t = 0; if (hipEventElapsedTime(&t, marks.front().second, marks.back().second) != hipSuccess) t = -1;
+            names.push_back("total"); ms.push_back(t);
         }
     }
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
@@ -61,7 +85,9 @@ struct msm_workspace { dev_buf hist, offsets, cursor, sorted, buckets, chunk_buc
 
 struct xhe_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
+    hipStream_t side[2] = {nullptr, nullptr};     // [0] point decode + ledger scan, [1] signatures; all at the default priority
+    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_side_done[2] = {nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -169,19 +195,23 @@ xhe_ctx *xhe_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete ctx; return nullptr; }
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_side_done[0], &ctx->ev_side_done[1]})
+        ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
 }
 
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.cursor,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts})
         b->release();
     ctx->timer.release();
-    (void)hipStreamDestroy(ctx->stream);
+    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_side_done[0], ctx->ev_side_done[1]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -399,17 +429,30 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *tx_err = B->tx_err.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
     const u32 *sd = B->seed.as<u32>();
 
-    HIPCHK(ctx, tm.mark("decode", st));
-    launch_decode_list(st, bytes, B->decs.as<dev_dec>(), n_dec, hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.mark("transcript", st));
-    launch_transcript(st, bytes, txs, cms, xfers, n_txs, chal, tx_err, rp_err);
-    HIPCHK(ctx, tm.mark("ledger_scan", st));
-    launch_ledger_scan(st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
+    // side stream 0: decode every point of the batch, then the ledger as a prefix sum
+    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1];
+    HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode", s0));
+    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), n_dec, hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close(s0));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s0));
+    HIPCHK(ctx, tm.open("ledger_scan", s0));
+    launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
                        B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok, n_slots,
                        B->final_cts.as<u32>());
-    HIPCHK(ctx, tm.mark("signatures", st));
-    launch_blake3_preimages(st, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
-    launch_schnorr(st, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(), B->ms_hash.as<u8>(), tx_err);
+    HIPCHK(ctx, tm.close(s0));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));
+    // side stream 1: signatures (need the decoded keys)
+    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_decoded, 0));
+    HIPCHK(ctx, tm.open("signatures", s1));
+    launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
+    launch_schnorr(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(), B->ms_hash.as<u8>(), tx_err);
+    HIPCHK(ctx, tm.close(s1));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
+    // main stream: transcripts (over the compressed bytes only), then the proof scalars
+    HIPCHK(ctx, tm.mark("transcript", st));
+    launch_transcript(st, bytes, txs, cms, xfers, n_txs, chal, tx_err, rp_err);
     HIPCHK(ctx, tm.mark("sigma_scalars", st));
     launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
     launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
@@ -425,12 +468,16 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 sum_blocks = std::min<u32>(128, (n_parts + 255) / 256);
     launch_sc_sum_partial(st, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
     launch_static_terms(st, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap, hb.static_term_off, scalars, term_point);
+    HIPCHK(ctx, tm.mark("join_points", st));
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[0], 0));
     HIPCHK(ctx, tm.mark("point_errors", st));
     launch_point_errors(st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipGetLastError());
     // merged multiscalar check: sigma terms + range-proof terms + static generators
     int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, true);
     if (rc) return rc;
+    HIPCHK(ctx, tm.mark("join_signatures", st));
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
     HIPCHK(ctx, tm.mark("verdict", st));
     launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
     HIPCHK(ctx, tm.mark("end", st));
