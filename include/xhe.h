@@ -4,8 +4,9 @@
  * are the Rust calls named beside each entry point.  Every entry point takes plain pointers and sizes;
  * all multi-byte integers in buffers are little-endian unless stated; all buffers are caller-owned
  * host memory unless the name says "_dev".  Return value: 0 = the call ran (the verdict is in the out
- * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU and one HIP stream and
- * must not be used from two threads at once; different contexts are independent.
+ * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns three HIP streams
+ * there, all at the default priority) and must not be used from two threads at once; different contexts
+ * are independent.
  */
 #ifndef XHE_H
 #define XHE_H
@@ -117,7 +118,7 @@ typedef struct xhe_verdict {
 
 /* Verifies the batch against the ledger snapshot `in` (BlockchainVerificationState of verify.rs:25-77,
  * flattened).  On accept `out` (may be NULL) receives the ledger after all transactions were applied in
- * order.  Differences from the reference, both documented in DESIGN.md: on reject `out` is not written
+ * order.  Two deliberate differences from the reference: on reject `out` is not written
  * (the reference leaves its state half-updated), and an unknown account or asset is XHE_ERR_STATE (the
  * reference's mock ledger panics).  rng_seed seeds the batch-factor generator (the reference draws
  * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it. */
@@ -136,7 +137,8 @@ int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *batch, const xhe_ledger_o
 void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
 
 /* Per-stage GPU time of the last xhe_batch_verify / xhe_msm_vartime on this context, measured with HIP
- * events on the context's stream.  names/ms arrays of length cap; returns the number of stages. */
+ * events on the stream each stage runs on (stages on different streams overlap; "total" spans the main
+ * stream).  names/ms arrays of length cap; returns the number of stages. */
 int32_t xhe_last_stage_times(const xhe_ctx *ctx, const char **names, float *ms, int32_t cap);
 
 #ifdef __cplusplus
