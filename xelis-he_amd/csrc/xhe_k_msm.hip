@@ -344,23 +344,82 @@ __global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict
     if (lane == 0) ge_store(win_out + 32ull * w, R);
 }
 
-// Horner over the windows, most significant first; writes the compressed result and the identity flag
-__global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, msm_plan p, u32 *__restrict__ out_words /*8*/, u32 *__restrict__ out_flag,
-                                                   u32 *__restrict__ out_point /*32 words, may be null*/) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ---- four waves sharing one point computation --------------------------------------------------------
+// The 252 doublings of the Horner stage are one dependent chain; a lone wave issues one field product
+// after the other (about 1.5 k cycles each, eight per doubling).  Here the four waves of a 256-thread
+// workgroup each compute one of the four independent products of a phase and trade results through LDS,
+// so a doubling costs two products plus two barriers.  Every lane of a wave holds the same values.
+struct coop_exchange { u32 w[2][4][10]; };
+__device__ __forceinline__ void coop_put(u32 *slot, const fe &v) {
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) slot[i] = v.v[i];
+    }
+}
+__device__ __forceinline__ fe coop_get(const u32 *slot) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = slot[i];
+    return r;
+}
+template <int ME, int MF, int MG, int MH>
+__device__ __forceinline__ ge coop_from_completed(const fe_t<ME> &E, const fe_t<MF> &F, const fe_t<MG> &G, const fe_t<MH> &H, u32 role, coop_exchange &x) {
+    fe mine;
+    if (role == 0) mine = fe_mul(E, F); else if (role == 1) mine = fe_mul(G, H); else if (role == 2) mine = fe_mul(F, G); else mine = fe_mul(E, H);
+    coop_put(x.w[1][role], mine);
+    __syncthreads();
+    ge r;
+    r.X = coop_get(x.w[1][0]); r.Y = coop_get(x.w[1][1]); r.Z = coop_get(x.w[1][2]); r.T = coop_get(x.w[1][3]);
+    return r;
+}
+__device__ __forceinline__ ge coop_double(const ge &p, u32 role, coop_exchange &x) {
+    fe mine;
+    if (role == 0) mine = fe_sq(p.X); else if (role == 1) mine = fe_sq(p.Y); else if (role == 2) mine = fe_sq(p.Z); else mine = fe_sq(fe_add(p.X, p.Y));
+    coop_put(x.w[0][role], mine);
+    __syncthreads();
+    fe A = coop_get(x.w[0][0]), B = coop_get(x.w[0][1]), ZZ = coop_get(x.w[0][2]), S = coop_get(x.w[0][3]);
+    auto C = fe_add(ZZ, ZZ);
+    auto H = fe_add(A, B);
+    auto E = fe_sub(S, H);
+    auto G = fe_sub(B, A);
+    fe F = fe_reduce(fe_sub(C, G));
+    return coop_from_completed(E, F, G, H, role, x);
+}
+__device__ __forceinline__ ge coop_add(const ge &p, const ge &q, u32 role, coop_exchange &x) {
+    fe mine;
+    if (role == 0) mine = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
+    else if (role == 1) mine = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    else if (role == 2) mine = fe_mul(fe_mul(p.T, fe_c_d2()), q.T);
+    else mine = fe_mul(p.Z, q.Z);
+    coop_put(x.w[0][role], mine);
+    __syncthreads();
+    fe A = coop_get(x.w[0][0]), B = coop_get(x.w[0][1]), C = coop_get(x.w[0][2]), ZZ = coop_get(x.w[0][3]);
+    auto D = fe_add(ZZ, ZZ);
+    return coop_from_completed(fe_sub(B, A), fe_sub(D, C), fe_add(D, C), fe_add(B, A), role, x);
+}
+
+// Horner over the windows, most significant first, one workgroup of four waves; writes the identity flag
+// and, when out_words is not null, the compressed result
+__global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win, msm_plan p, u32 *__restrict__ out_words /*8, may be null*/,
+                                                    u32 *__restrict__ out_flag) {
+    __shared__ coop_exchange x;
+    const u32 role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     ge R = ge_load(win + 32ull * (p.W - 1));
     for (int w = (int)p.W - 2; w >= 0; w--) {
-        for (u32 k = 0; k < p.c; k++) R = ge_double(R);
-        R = ge_add(R, ge_load(win + 32ull * w));
+        for (u32 k = 0; k < p.c; k++) R = coop_double(R, role, x);
+        R = coop_add(R, ge_load(win + 32ull * w), role, x);
     }
-    u32 enc[8]; ristretto_encode_words(enc, R);
-    for (int i = 0; i < 8; i++) out_words[i] = enc[i];
-    out_flag[0] = ge_ristretto_is_identity(R) ? 1u : 0u;
-    if (out_point) ge_store(out_point, R);
+    if (role != 0) return;
+    bool ident = ge_ristretto_is_identity(R);
+    if (out_words) {
+        u32 enc[8]; ristretto_encode_words(enc, R);
+        if (threadIdx.x == 0) for (int i = 0; i < 8; i++) out_words[i] = enc[i];
+    }
+    if (threadIdx.x == 0) out_flag[0] = ident ? 1u : 0u;
 }
 
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, msm_mark_fn mark, void *mark_user) {
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, msm_mark_fn mark, void *mark_user) {
 #define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
@@ -385,7 +444,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets, p, ws.segs);
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
     MARK("msm_horner");
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins, p, d_result, d_result + 8, (u32 *)nullptr);
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
 #undef MARK
     return hipGetLastError();
 }

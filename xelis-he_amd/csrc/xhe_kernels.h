@@ -22,9 +22,9 @@ struct msm_ws {
 struct msm_ws_bytes { u64 hist, offsets, cursor, sorted, buckets, chunk_bucket, chunk_sums, big_list, segs, wins; };
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
-// result: 8 words of encoding at d_result[0..8), identity flag at d_result[8]
+// result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, msm_mark_fn mark, void *mark_user);
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, msm_mark_fn mark, void *mark_user);
 
 // points
 void launch_decode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok);

@@ -124,7 +124,8 @@ static void set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) ctx->erro
 // into d_result[0..8], d_result[8].
 static hipError_t timer_mark(void *user, const char *name) { xhe_ctx *ctx = (xhe_ctx *)user; return ctx->timer.mark(name, ctx->stream); }
 
-static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool timing) {
+static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool want_encoding,
+                          bool timing) {
     msm_workspace &ws = ctx->msm;
     msm_plan p = msm_make_plan(n);
     if (n * p.W > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
@@ -140,7 +141,7 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.wins.reserve(need.wins));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.cursor.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), nullptr, ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
-    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, timing ? timer_mark : nullptr, ctx));
+    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, timing ? timer_mark : nullptr, ctx));
     return 0;
 }
 
@@ -275,7 +276,7 @@ int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, cons
         launch_count_bad(st, ctx->ok.as<u8>(), n, ctx->result.as<u32>() + 12);
         launch_reduce_scalars(st, ctx->scalars.as<u32>(), n);
     }
-    int32_t rc = msm_device(ctx, ctx->scalars.as<u32>(), ctx->niels.as<u32>(), nullptr, n, n, ctx->result.as<u32>(), true);
+    int32_t rc = msm_device(ctx, ctx->scalars.as<u32>(), ctx->niels.as<u32>(), nullptr, n, n, ctx->result.as<u32>(), true, true);
     if (rc) return rc;
     HIPCHK(ctx, ctx->timer.mark("end", st));
     u32 host[16];
@@ -474,7 +475,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_point_errors(st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipGetLastError());
     // merged multiscalar check: sigma terms + range-proof terms + static generators
-    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, true);
+    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, false, true);
     if (rc) return rc;
     HIPCHK(ctx, tm.mark("join_signatures", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
@@ -502,7 +503,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         // reuse k_static_terms with nm_cap = 0: writes only the B and H scalars
         launch_static_terms(st, B->gh_sums.as<u32>(), sb, B->rp_acc.as<u32>(), 0u, n_sig_terms, s2.as<u32>(), tp2.as<u32>());
         HIPCHK(ctx, hipMemsetAsync(r2.p, 0, 64, st));
-        rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false);
+        rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false, false);
         u32 h2[16];
         if (rc == 0) { hipError_t e = hipMemcpyAsync(h2, r2.p, 64, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipStreamSynchronize(st); if (e != hipSuccess) rc = XHE_E_HIP; }
         s2.release(); tp2.release(); r2.release();
