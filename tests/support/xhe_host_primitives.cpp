@@ -4,6 +4,8 @@
 #include <string.h>
 #include "../../xelis-he_amd/csrc/xhe_ge.h"
 #include "../../xelis-he_amd/csrc/xhe_hash.h"
+#include "../../xelis-he_amd/csrc/xhe_record.h"
+#include "../../xelis-he_amd/csrc/xhe_transcript_template.h"
 using namespace xhe;
 
 extern "C" {
@@ -73,5 +75,45 @@ u64 xt_merlin_script(const char *proto_label, const u8 *ops, u64 ops_len, u8 *ou
         else { if (w + len > out_cap) return 0; t.challenge_bytes(label, out + w, len); w += len; }
     }
     return w;
+}
+// Replays the transcript template of a record on the CPU: gathers every block's 168 bytes through the
+// descriptors, XORs them into a Keccak state, permutes, and squeezes the challenges where the template says.
+// Returns the number of challenges written (32 bytes each), -1 malformed record, -2 unsupported shape.
+// n_blocks_out / n_checks_failed_out (nullable) report the block count and the all-zero encodings found.
+long long xt_transcript_template_challenges(const u8 *rec, u64 len, u8 *out32, u64 cap, u32 *n_blocks_out, u32 *zero_checks_out) {
+    tx_record t;
+    if (!record_parse(t, rec, len)) return -1;
+    transcript_shape sh{t.type, t.n_commitments, (u32)t.transfer_off.size(), t.n_items, t.m(), t.lg()};
+    if (!transcript_shape_supported(sh)) return -2;
+    std::vector<u32> tmpl, seg;
+    tmpl.assign(3, 0);                                  // some unrelated words in front: offsets must be honoured
+    u32 base = build_transcript_template(tmpl, sh);
+    transcript_segments(seg, t);
+    const u32 *hdr = tmpl.data() + base;
+    u32 n_blocks = hdr[TT_H_BLOCKS];
+    const u32 *chal_after = hdr + TT_H_WORDS, *checks = chal_after + n_blocks, *desc = tmpl.data() + hdr[TT_H_DESC];
+    if (n_blocks_out) *n_blocks_out = n_blocks;
+    u32 zeros = 0;
+    for (u32 c = 0; c < hdr[TT_H_CHECKS]; c++) {
+        const u8 *p = rec + seg[checks[2 * c] >> 16] + (checks[2 * c] & 0xffffu);
+        u8 acc = 0; for (int k = 0; k < 32; k++) acc |= p[k];
+        if (!acc) zeros++;
+    }
+    if (zero_checks_out) *zero_checks_out = zeros;
+    keccak_state st; st.clear();
+    long long n = 0;
+    for (u32 b = 0; b < n_blocks; b++) {
+        for (u32 j = 0; j < TT_BLOCK_BYTES; j++) {
+            u32 d = desc[b * TT_BLOCK_BYTES + j];
+            st.bytes[j] ^= (d & TT_CONST) ? (u8)d : rec[seg[d >> 16] + (d & 0xffffu)];
+        }
+        st.permute();
+        if (chal_after[b] != TT_NONE) {
+            if ((u64)chal_after[b] < cap) { sc x = sc_from_wide_bytes(st.bytes); sc_tobytes(out32 + 32 * chal_after[b], x); }
+            for (int j = 0; j < 64; j++) st.bytes[j] = 0;
+            n++;
+        }
+    }
+    return n;
 }
 }

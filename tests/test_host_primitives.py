@@ -115,3 +115,22 @@ def test_merlin_vs_oracle(hostlib, oracle):
     na = hostlib.xt_merlin_script(b"transaction-proof", s, len(s), a, 8192)
     nb = oracle.xo_merlin_script(b"transaction-proof", s, len(s), b, 8192)
     assert na == nb and na > 0 and bytes(a[:na]) == bytes(b[:nb])
+
+
+def test_transcript_template_matches_transcript(oracle, hostlib):
+    """The unrolled transcript (block descriptors replayed over a plain Keccak state) yields the challenges
+    of the operation-by-operation Merlin transcript, for every kind of transaction in the fixtures."""
+    import ctypes
+    import golden_io
+    hostlib.xt_transcript_template_challenges.restype = ctypes.c_longlong
+    seen = 0
+    for case in golden_io.tx_cases():
+        for rec_hex, want in zip(case["records"], case["expect"]["challenges"]):
+            rec = bytes.fromhex(rec_hex)
+            out = buf(32 * 64)
+            blocks, zeros = ctypes.c_uint32(), ctypes.c_uint32()
+            n = hostlib.xt_transcript_template_challenges(rec, ctypes.c_uint64(len(rec)), out, ctypes.c_uint64(64), ctypes.byref(blocks), ctypes.byref(zeros))
+            assert n * 64 == len(want) and bytes(out)[:32 * n].hex() == want, case["name"]
+            assert zeros.value == 0 and blocks.value > 10
+            seen += 1
+    assert seen >= 15

@@ -16,6 +16,7 @@
 #include <vector>
 #include "../../include/xhe.h"
 #include "xhe_record.h"
+#include "xhe_transcript_template.h"
 #include "xhe_verify_types.h"
 
 namespace xhe {
@@ -42,6 +43,9 @@ struct host_batch {
     std::vector<u32> ms_hash_tx;           // transactions whose pre-image BLAKE3 digest is needed
     std::vector<std::vector<u32>> lg_groups;   // transactions by lg (index = lg)
     std::vector<int64_t> multisig_set_by;  // per account
+    std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
+    std::vector<u32> segs;                 // per-transaction segment tables
+    std::vector<u32> serial_txs;           // transactions whose transcript runs in the serial kernel
     u32 n_static = 0, nm_cap = 0;
     u32 n_points = 0;                      // static + decoded + emitted
     u32 emit_base = 0, n_emit = 0;         // emitted ciphertext points (2 per commitment)
@@ -126,6 +130,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     };
 
     hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE);
+    std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_of;
     hb.lg_groups.assign(16, {});
     u32 term = 0, chal = 0;
     auto raise = [&](u64 i, u32 key) { if (key < hb.tx_err[i]) hb.tx_err[i] = key; };
@@ -150,6 +155,15 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         d.chal_off = chal; chal += 2 * A + 2 * T + 4 + lg;
         d.rp_term_off = term; term += 4 + 2 * lg + A + T;
         if (lg <= 15) { d.rp_row = (u32)hb.lg_groups[lg].size(); hb.lg_groups[lg].push_back((u32)i); }
+        {
+            transcript_shape sh{t.type, A, T, t.n_items, d.m, lg};
+            if (transcript_shape_supported(sh)) {
+                auto it = tmpl_of.find(sh);
+                d.tmpl_off = it != tmpl_of.end() ? it->second : (tmpl_of[sh] = build_transcript_template(hb.tmpl, sh));
+                d.seg_off = (u32)hb.segs.size();
+                transcript_segments(hb.segs, t);
+            } else { d.tmpl_off = TT_NONE; hb.serial_txs.push_back((u32)i); }
+        }
 
         // per-tx points: range proof, commitments, transfers
         d.rp_pt = new_point(rec + t.rp_off, (u32)i);

@@ -105,13 +105,13 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs;
+    dev_buf bytes, txs, cms, xfers, decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed})
             b->release();
@@ -321,6 +321,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     B->group_off[16] = (u32)group_txs.size();
 #define UP(buf, vec) do { hipError_t e_ = upload_vec(B->buf, vec, st); if (e_ != hipSuccess) { set_error(ctx, std::string("upload " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
     UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
+    UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs);
     UP(tx_err0, hb.tx_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
     u64 n_slots = hb.slot_of_used.size();
@@ -453,7 +454,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
     // main stream: transcripts (over the compressed bytes only), then the proof scalars
     HIPCHK(ctx, tm.mark("transcript", st));
-    launch_transcript(st, bytes, txs, cms, xfers, n_txs, chal, tx_err, rp_err);
+    launch_transcript(st, bytes, txs, cms, xfers, n_txs, B->tmpl.as<u32>(), B->segs.as<u32>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
     HIPCHK(ctx, tm.mark("sigma_scalars", st));
     launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
     launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);

@@ -1,5 +1,5 @@
 // Device-resident tables of one uploaded batch: what the host ingest (xhe_ingest.h) lays out and the
-// verification kernels (xhe_verify.hip.h) consume.  All offsets into `bytes` are absolute byte offsets
+// verification kernels (xhe_k_*.hip) consume.  All offsets into `bytes` are absolute byte offsets
 // into one device byte buffer holding the transaction records followed by the ledger's account keys,
 // balance ciphertexts and multisig signer keys.
 //
@@ -35,6 +35,8 @@ struct dev_tx {
     u32 src_pt;              // point index of the source key
     u32 hash_idx;            // index into ms_hash[] (BLAKE3 of the pre-image) or 0xffffffff
     u32 rp_row;              // row of this tx inside its nm-group's scalar matrix
+    u32 tmpl_off;            // word offset of the transaction's transcript template, 0xffffffff: serial transcript kernel
+    u32 seg_off;             // first entry of its segment table (record-relative offsets)
     u32 reserved;
 };
 
