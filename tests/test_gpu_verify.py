@@ -215,6 +215,24 @@ def test_eight_transfers(engine, oracle):
     assert lg.balance_decrypts_to(alice.pubkey, ASSET55, 77 - 4 - 8)
 
 
+def test_seventeen_transfers_then_small(engine, oracle):
+    """18 value commitments -> 2048 generators per side: beyond the fixed-base tables the context keeps, so the
+    static generators go through the bucket pipeline; a small transaction afterwards is back on the tables."""
+    alice = Account([(NATIVE, 5000)], "big-a")
+    dests = [Account([(NATIVE, 0)], "big-d%d" % i) for i in range(4)]
+    ts = [TransferBuilder(dests[i % 4].pubkey, 1 + i) for i in range(17)]
+    tx = TransactionBuilder(1, alice.pubkey, ("transfers", ts), 2, 0).build({NATIVE: 5000}, alice.keypair, "seventeen", alice)
+    ledger = Ledger([alice] + dests)
+    lg, _ = check_same(engine, oracle, [tx], ledger, expect_accept=True)
+    assert lg.balance_decrypts_to(alice.pubkey, NATIVE, 5000 - 2 - sum(range(1, 18)))
+    bad = bytearray(tx.record)
+    bad[-100] ^= 1
+    check_same(engine, oracle, [Transaction(bytes(bad))], ledger, expect_accept=False)
+    bob, carol = Account([(NATIVE, 100)], "big-b"), Account([(NATIVE, 0)], "big-c")
+    small = TransactionBuilder(1, bob.pubkey, ("transfers", [TransferBuilder(carol.pubkey, 10)]), 1, 0).build({NATIVE: 100}, bob.keypair, "small", bob)
+    check_same(engine, oracle, [small], Ledger([bob, carol]), expect_accept=True)
+
+
 def test_synthetic_batch(engine, oracle):
     sb = SyntheticBatch(96, n_transfers=1, n_senders=8, seed=b"synth-96")
     lib = engine.lib

@@ -400,8 +400,8 @@ __device__ __forceinline__ ge coop_add(const ge &p, const ge &q, u32 role, coop_
 
 // Horner over the windows, most significant first, one workgroup of four waves; writes the identity flag
 // and, when out_words is not null, the compressed result
-__global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win, msm_plan p, u32 *__restrict__ out_words /*8, may be null*/,
-                                                    u32 *__restrict__ out_flag) {
+__global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win, msm_plan p, const u32 *__restrict__ extra_point /*may be null*/,
+                                                    u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag) {
     __shared__ coop_exchange x;
     const u32 role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     ge R = ge_load(win + 32ull * (p.W - 1));
@@ -409,6 +409,7 @@ __global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win,
         for (u32 k = 0; k < p.c; k++) R = coop_double(R, role, x);
         R = coop_add(R, ge_load(win + 32ull * w), role, x);
     }
+    if (extra_point) R = coop_add(R, ge_load(extra_point), role, x);
     if (role != 0) return;
     bool ident = ge_ristretto_is_identity(R);
     if (out_words) {
@@ -418,8 +419,66 @@ __global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win,
     if (threadIdx.x == 0) out_flag[0] = ident ? 1u : 0u;
 }
 
+// ---- fixed points: table look-ups instead of buckets ---------------------------------------------------
+__device__ __forceinline__ ge block_point_sum(ge acc, u32 (*part)[40]) {
+    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) {
+        ge o = ge_shfl_down(acc, d);
+        ge sum = ge_add(acc, o);
+        acc = ge_select(acc, sum, lane < d);
+    }
+    if (lane == 0 && wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) { part[wave - 1][i] = acc.X.v[i]; part[wave - 1][10 + i] = acc.Y.v[i]; part[wave - 1][20 + i] = acc.Z.v[i]; part[wave - 1][30 + i] = acc.T.v[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (u32 w = 0; w + 1 < (blockDim.x >> 6); w++) {
+            ge o;
+#pragma unroll
+            for (int i = 0; i < 10; i++) { o.X.v[i] = part[w][i]; o.Y.v[i] = part[w][10 + i]; o.Z.v[i] = part[w][20 + i]; o.T.v[i] = part[w][30 + i]; }
+            acc = ge_add(acc, o);
+        }
+    }
+    return acc;                                       // thread 0 holds the workgroup's sum
+}
+// thread per (fixed point, byte of its scalar): the table entry for that byte; workgroup sums to partials[]
+// scalars: B, H, G_vec[nm_cap], H_vec[nm_cap]; the tables hold B, H, G_vec[table_cap], H_vec[table_cap]
+__global__ void __launch_bounds__(256, 2) k_static_eval(const u32 *__restrict__ gen_tab, const u32 *__restrict__ scalars, u32 nm_cap, u32 table_cap,
+                                                        u32 *__restrict__ partials) {
+    __shared__ u32 part[3][40];
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    ge acc = ge_identity();
+    if (g < 32 * (2 + 2 * nm_cap)) {
+        u32 term = g >> 5, w = g & 31;
+        u32 base = term < 2 + nm_cap ? term : term - nm_cap + table_cap;
+        u32 byte = (scalars[8ull * term + (w >> 2)] >> ((w & 3) * 8)) & 255;
+        if (byte) acc = ge_madd(acc, ge_niels_load(gen_tab + 32ull * (((u64)base * 32 + w) * 256 + byte)));
+    }
+    acc = block_point_sum(acc, part);
+    if (threadIdx.x == 0) ge_store(partials + 32ull * blockIdx.x, acc);
+}
+__global__ void __launch_bounds__(64) k_static_sum(const u32 *__restrict__ partials, u32 n, u32 *__restrict__ out) {
+    u32 lane = threadIdx.x;
+    ge acc = ge_identity();
+    for (u32 i = lane; i < n; i += 64) acc = ge_add(acc, ge_load(partials + 32ull * i));
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) {
+        ge o = ge_shfl_down(acc, d);
+        ge sum = ge_add(acc, o);
+        acc = ge_select(acc, sum, lane < d);
+    }
+    if (lane == 0) ge_store(out, acc);
+}
+void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, u32 nm_cap, u32 table_cap, u32 *partials, u32 *out) {
+    u32 blocks = grid_for(32ull * (2 + 2 * nm_cap), 256);
+    hipLaunchKernelGGL(k_static_eval, dim3(blocks), dim3(256), 0, st, gen_tab, scalars, nm_cap, table_cap, partials);
+    hipLaunchKernelGGL(k_static_sum, dim3(1), dim3(64), 0, st, partials, blocks, out);
+}
+
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, msm_mark_fn mark, void *mark_user) {
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const u32 *extra_point, hipEvent_t extra_ready, msm_mark_fn mark, void *mark_user) {
 #define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
@@ -444,7 +503,8 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets, p, ws.segs);
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
     MARK("msm_horner");
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
+    if (extra_ready && (e = hipStreamWaitEvent(st, extra_ready, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
 #undef MARK
     return hipGetLastError();
 }

@@ -92,11 +92,13 @@ __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ b
 }
 
 
-__global__ void __launch_bounds__(256, 2) k_build_fixed_table(const u32 *__restrict__ base_niels, u32 n_windows, u32 *__restrict__ tab) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_windows * 256) return;
-    u32 w = g >> 8, b = g & 255;
-    ge p = ge_from_niels_affine(ge_niels_load(base_niels));
+// Fixed-base tables: tab[(base * n_windows + w) * 256 + b] = b * 2^(8w) * P_base as affine Niels, for
+// n_bases points given as affine Niels records.  Thread per entry.
+__global__ void __launch_bounds__(256, 2) k_build_fixed_table(const u32 *__restrict__ base_niels, u32 n_bases, u32 n_windows, u32 *__restrict__ tab) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (u64)n_bases * n_windows * 256) return;
+    u32 b = (u32)g & 255, w = (u32)((g >> 8) % n_windows), base = (u32)((g >> 8) / n_windows);
+    ge p = ge_from_niels_affine(ge_niels_load(base_niels + 32ull * base));
     for (u32 k = 0; k < 8 * w; k++) p = ge_double(p);
     ge r = ge_identity();
     for (int bit = 7; bit >= 0; bit--) { r = ge_double(r); if ((b >> bit) & 1) r = ge_add(r, p); }
@@ -142,6 +144,19 @@ __global__ void __launch_bounds__(256) k_verdict(const u32 *__restrict__ tx_err,
 }
 
 
+__global__ void __launch_bounds__(256) k_setup(setup_jobs jobs) {
+    const int j = blockIdx.y;
+    u32 *dst = jobs.dst[j]; const u32 *src = jobs.src[j]; const u64 n = jobs.n_words[j]; const u32 v = jobs.value[j];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src ? src[i] : v;
+    if (j == 0 && blockIdx.x == 0 && threadIdx.x < 8 && jobs.seed_dst) jobs.seed_dst[threadIdx.x] = jobs.seed[threadIdx.x];
+}
+void launch_setup(hipStream_t st, const setup_jobs &jobs) {
+    if (jobs.n <= 0) return;
+    u64 most = 1;
+    for (int j = 0; j < jobs.n; j++) if (jobs.n_words[j] > most) most = jobs.n_words[j];
+    unsigned bx = grid_for(most, 256 * 4); if (bx > 1024) bx = 1024; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_setup, dim3(bx, jobs.n), dim3(256), 0, st, jobs);
+}
 void launch_decode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok) { if (n) hipLaunchKernelGGL(k_decode_xyzt, dim3(grid_for(n, 256)), dim3(256), 0, st, in, n, out, ok); }
 void launch_decode_niels(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok) { if (n) hipLaunchKernelGGL(k_decode_niels, dim3(grid_for(n, 256)), dim3(256), 0, st, in, n, out, ok); }
 void launch_encode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out) { if (n) hipLaunchKernelGGL(k_encode_xyzt, dim3(grid_for(n, 256)), dim3(256), 0, st, in, n, out); }
@@ -151,8 +166,8 @@ void launch_base_points(hipStream_t st, u32 *out) { hipLaunchKernelGGL(k_base_po
 void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pts) {
     if (n_parties) hipLaunchKernelGGL(k_bp_generators, dim3(grid_for(2 * n_parties, 64)), dim3(64), 0, st, 0u, n_parties, cap, static_pts);
 }
-void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_windows, u32 *tab) {
-    hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for(n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_windows, tab);
+void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab) {
+    if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, u32 n, u32 pt_base, u32 *pts, u8 *ok) {
     if (n) hipLaunchKernelGGL(k_decode_list, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, decs, n, pt_base, pts, ok);

@@ -23,8 +23,25 @@ struct msm_ws_bytes { u64 hist, offsets, cursor, sorted, buckets, chunk_bucket, 
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
 // result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)
+// extra_point (nullable): an XYZT point added to the sum before the identity test, valid once extra_ready (nullable) has fired
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, msm_mark_fn mark, void *mark_user);
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const u32 *extra_point, hipEvent_t extra_ready, msm_mark_fn mark, void *mark_user);
+// Sum of scalars[j] * P_j over the static generators B, H, G_vec[nm_cap], H_vec[nm_cap] from 32 x 256 fixed-base tables laid out
+// for capacity table_cap: partial sums per workgroup, then one wave.  partials: ceil(32 (2 + 2 nm_cap) / 256) XYZT records; out: one.
+void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, u32 nm_cap, u32 table_cap, u32 *partials, u32 *out);
+static constexpr u32 GEN_TABLE_CAP_MAX = 1024;    // generators per side up to which the context keeps tables (1 MiB per generator)
+
+// One launch for the fills and copies that start a verification: job j writes n_words 32-bit words to dst,
+// copied from src or, when src is null, set to value; the last job slot carries the batch-factor seed.
+struct setup_jobs {
+    static constexpr int MAX = 12;
+    u32 *dst[MAX]; const u32 *src[MAX]; u64 n_words[MAX]; u32 value[MAX];
+    int n = 0;
+    u32 seed[8]; u32 *seed_dst = nullptr;
+    void fill(void *d, u32 v, u64 words) { dst[n] = (u32 *)d; src[n] = nullptr; n_words[n] = words; value[n] = v; n++; }
+    void copy(void *d, const void *s, u64 words) { dst[n] = (u32 *)d; src[n] = (const u32 *)s; n_words[n] = words; value[n] = 0; n++; }
+};
+void launch_setup(hipStream_t st, const setup_jobs &jobs);
 
 // points
 void launch_decode_xyzt(hipStream_t st, const u32 *in, u64 n, u32 *out, u8 *ok);
@@ -34,7 +51,7 @@ void launch_reduce_scalars(hipStream_t st, u32 *s, u64 n);
 void launch_count_bad(hipStream_t st, const u8 *ok, u64 n, u32 *out);
 void launch_base_points(hipStream_t st, u32 *out);
 void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pts);
-void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_windows, u32 *tab);
+void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab);
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, u32 n, u32 pt_base, u32 *pts, u8 *ok);
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
 void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp);

@@ -86,8 +86,8 @@ struct msm_workspace { dev_buf hist, offsets, cursor, sorted, buckets, chunk_buc
 struct xhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
-    hipStream_t side[2] = {nullptr, nullptr};     // [0] point decode + ledger scan, [1] signatures; all at the default priority
-    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_side_done[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // [0] point decode + ledger scan, [1] signatures, [2] static-generator scalars; default priority
+    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -98,6 +98,9 @@ struct xhe_ctx {
     dev_buf gtab, htab;        // fixed-base tables: 8 x 256 multiples of G, 32 x 256 multiples of H
     dev_buf static_pts;        // B, H, G_vec[cap], H_vec[cap]
     u32 static_cap = 0;        // generators per side currently held
+    dev_buf gen_tab;           // 32 x 256 fixed-base table of every static point (static_cap <= GEN_TABLE_CAP_MAX), else empty
+    u32 gen_tab_cap = 0;       // the capacity gen_tab was built for, 0 = none
+    dev_buf static_partials, static_sum;
     bool tables_ready = false;
 };
 
@@ -125,7 +128,7 @@ static void set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) ctx->erro
 static hipError_t timer_mark(void *user, const char *name) { xhe_ctx *ctx = (xhe_ctx *)user; return ctx->timer.mark(name, ctx->stream); }
 
 static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool want_encoding,
-                          bool timing) {
+                          bool timing, const u32 *extra_point = nullptr, hipEvent_t extra_ready = nullptr) {
     msm_workspace &ws = ctx->msm;
     msm_plan p = msm_make_plan(n);
     if (n * p.W > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
@@ -141,7 +144,7 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.wins.reserve(need.wins));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.cursor.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), nullptr, ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
-    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, timing ? timer_mark : nullptr, ctx));
+    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, extra_point, extra_ready, timing ? timer_mark : nullptr, ctx));
     return 0;
 }
 
@@ -153,8 +156,8 @@ static int32_t ensure_tables(xhe_ctx *ctx, u32 cap) {
         HIPCHK(ctx, ctx->gtab.reserve(8 * 256 * 128));
         HIPCHK(ctx, ctx->htab.reserve(32 * 256 * 128));
         launch_base_points(st, ctx->base_pts.as<u32>());
-        launch_build_fixed_table(st, ctx->base_pts.as<u32>(), 8u, ctx->gtab.as<u32>());
-        launch_build_fixed_table(st, ctx->base_pts.as<u32>() + 32, 32u, ctx->htab.as<u32>());
+        launch_build_fixed_table(st, ctx->base_pts.as<u32>(), 1u, 8u, ctx->gtab.as<u32>());
+        launch_build_fixed_table(st, ctx->base_pts.as<u32>() + 32, 1u, 32u, ctx->htab.as<u32>());
         HIPCHK(ctx, hipGetLastError());
         ctx->tables_ready = true;
     }
@@ -169,6 +172,22 @@ static int32_t ensure_tables(xhe_ctx *ctx, u32 cap) {
         ctx->static_pts.release();
         ctx->static_pts = fresh;
         ctx->static_cap = cap;
+    }
+    // fixed-base tables of the static points (up to GEN_TABLE_CAP_MAX generators per side): the static part
+    // of the multiscalar check becomes look-ups
+    u32 tcap = std::min<u32>(ctx->static_cap, GEN_TABLE_CAP_MAX);
+    if (tcap > ctx->gen_tab_cap) {
+        ctx->gen_tab.release(); ctx->gen_tab_cap = 0;
+        u64 n_bases = 2ull + 2ull * tcap;
+        HIPCHK(ctx, ctx->gen_tab.reserve(n_bases * 32 * 256 * 128));
+        launch_build_fixed_table(st, ctx->static_pts.as<u32>(), 2 + tcap, 32u, ctx->gen_tab.as<u32>());                      // B, H, G_vec[0..tcap)
+        launch_build_fixed_table(st, ctx->static_pts.as<u32>() + 32ull * (2 + ctx->static_cap), tcap, 32u,
+                                 ctx->gen_tab.as<u32>() + 32ull * (2ull + tcap) * 32 * 256);                                    // H_vec[0..tcap)
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, ctx->static_partials.reserve((n_bases * 32 / 256 + 2) * 128));
+        HIPCHK(ctx, ctx->static_sum.reserve(128));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        ctx->gen_tab_cap = tcap;
     }
     return 0;
 }
@@ -196,8 +215,9 @@ xhe_ctx *xhe_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_side_done[0], &ctx->ev_side_done[1]})
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
+              hipStreamCreate(&ctx->side[2]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -206,13 +226,13 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.cursor,
-                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts})
+                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_side_done[0], ctx->ev_side_done[1]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -346,6 +366,10 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
         RS(rp_mat, worst);
     }
 #undef RS
+    // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
+    HIPCHK(ctx, hipMemcpyAsync(B->pts.p, ctx->static_pts.p, 256 + 128ull * hb.nm_cap, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256 + 128ull * hb.nm_cap, ctx->static_pts.as<u8>() + 256 + 128ull * ctx->static_cap, 128ull * hb.nm_cap,
+                               hipMemcpyDeviceToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return 0;
 }
@@ -402,21 +426,21 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     stage_timer &tm = ctx->timer;
     tm.begin();
     HIPCHK(ctx, tm.mark("setup", st));
-    HIPCHK(ctx, hipMemcpyAsync(B->seed.p, seed, 32, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(B->pts.p, ctx->static_pts.p, 256, hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256, ctx->static_pts.as<u8>() + 256, 128ull * hb.nm_cap, hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256 + 128ull * hb.nm_cap, ctx->static_pts.as<u8>() + 256 + 128ull * ctx->static_cap, 128ull * hb.nm_cap,
-                               hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(B->ok.p, 1, hb.n_points, st));
-    HIPCHK(ctx, hipMemcpyAsync(B->tx_err.p, B->tx_err0.p, 4ull * std::max<u32>(n_txs, 1), hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(B->rp_err.p, 0, 4ull * std::max<u32>(n_txs, 1), st));
-    HIPCHK(ctx, hipMemsetAsync(B->rp_acc.p, 0, 72ull * hb.nm_cap, st));
-    HIPCHK(ctx, hipMemsetAsync(B->emit_incl.p, 0, 256ull * (n_cm + 1), st));
-    HIPCHK(ctx, hipMemsetAsync(B->slot_base.p, 0, 256ull * (n_slots + 1), st));
-    HIPCHK(ctx, hipMemsetAsync(B->slot_final.p, 0, 256ull * (n_slots + 1), st));
-    HIPCHK(ctx, hipMemsetAsync(B->pts.as<u8>() + 128ull * hb.emit_base, 0, 128ull * hb.n_emit, st));
-    HIPCHK(ctx, hipMemsetAsync(B->verdict.p, 0xff, 16, st));
-    HIPCHK(ctx, hipMemsetAsync(B->verdict.as<u8>() + 16, 0, 48, st));
+    {
+        setup_jobs jobs;
+        memcpy(jobs.seed, seed, 32); jobs.seed_dst = B->seed.as<u32>();
+        jobs.fill(B->ok.p, 0x01010101u, (hb.n_points + 3) / 4);
+        jobs.copy(B->tx_err.p, B->tx_err0.p, std::max<u32>(n_txs, 1));
+        jobs.fill(B->rp_err.p, 0, std::max<u32>(n_txs, 1));
+        jobs.fill(B->rp_acc.p, 0, 18ull * hb.nm_cap);
+        jobs.fill(B->emit_incl.p, 0, 64ull * (n_cm + 1));
+        jobs.fill(B->slot_base.p, 0, 64ull * (n_slots + 1));
+        jobs.fill(B->slot_final.p, 0, 64ull * (n_slots + 1));
+        jobs.fill(B->pts.as<u32>() + 32ull * hb.emit_base, 0, 32ull * hb.n_emit);
+        jobs.fill(B->verdict.p, 0xffffffffu, 4);
+        jobs.fill(B->verdict.as<u32>() + 4, 0, 12);
+        launch_setup(st, jobs);
+    }
     if (n_txs == 0) {
         *verdict = {1, XHE_OK, -1};
         B->verified_ok = true;
@@ -460,23 +484,41 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
     HIPCHK(ctx, tm.mark("rangeproof_scalars", st));
     launch_rp_prep(st, bytes, txs, cms, xfers, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh + 18ull * (n_cm + n_xf), rp_err);
+    // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
+    // parts).  With fixed-base tables their whole contribution is evaluated on side stream 2 while the main
+    // stream sorts and accumulates the dynamic terms; without, they join the multiscalar check as terms.
+    const bool use_tables = ctx->gen_tab_cap != 0 && hb.nm_cap <= ctx->gen_tab_cap;
+    hipStream_t ss = use_tables ? ctx->side[2] : st;
+    if (use_tables) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_scalars, st));
+        HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_scalars, 0));
+        HIPCHK(ctx, tm.open("static_scalars", ss));
+    }
     for (u32 lg = 6; lg < 16; lg++) {
         u32 rows = (u32)hb.lg_groups[lg].size();
         if (!rows) continue;
         u32 rpt = rp_rows_per_thread(rows, lg), tiles = (rows + rpt - 1) / rpt;
-        launch_rp_matrix(st, B->group_txs.as<u32>() + B->group_off[lg], rows, rpt, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
-        launch_rp_colsum(st, B->rp_mat.as<u32>(), tiles, lg, hb.nm_cap, B->rp_acc.as<u32>());
+        launch_rp_matrix(ss, B->group_txs.as<u32>() + B->group_off[lg], rows, rpt, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
+        launch_rp_colsum(ss, B->rp_mat.as<u32>(), tiles, lg, hb.nm_cap, B->rp_acc.as<u32>());
     }
     u32 sum_blocks = std::min<u32>(128, (n_parts + 255) / 256);
-    launch_sc_sum_partial(st, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
-    launch_static_terms(st, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap, hb.static_term_off, scalars, term_point);
+    launch_sc_sum_partial(ss, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
+    launch_static_terms(ss, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap, hb.static_term_off, scalars, term_point);
+    if (use_tables) {
+        launch_static_eval(ss, ctx->gen_tab.as<u32>(), scalars + 8ull * hb.static_term_off, hb.nm_cap, ctx->gen_tab_cap, ctx->static_partials.as<u32>(),
+                           ctx->static_sum.as<u32>());
+        HIPCHK(ctx, tm.close(ss));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], ss));
+    }
     HIPCHK(ctx, tm.mark("join_points", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[0], 0));
     HIPCHK(ctx, tm.mark("point_errors", st));
     launch_point_errors(st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipGetLastError());
-    // merged multiscalar check: sigma terms + range-proof terms + static generators
-    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, false, true);
+    // merged multiscalar check: sigma terms + range-proof terms (+ static generators, unless their sum comes from the tables)
+    int32_t rc = use_tables ? msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.static_term_off, B->verdict.as<u32>() + 4, false, true, ctx->static_sum.as<u32>(),
+                                         ctx->ev_side_done[2])
+                            : msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, false, true);
     if (rc) return rc;
     HIPCHK(ctx, tm.mark("join_signatures", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
