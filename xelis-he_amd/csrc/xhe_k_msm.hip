@@ -3,9 +3,12 @@
 // mega-check (/root/reference/src/tx/verify.rs:504-513).
 //
 // Pipeline (every stage one launch over the whole problem):
-//   digits+histogram  thread per term: signed radix-2^c digits, one atomic count per (window, bucket)
-//   scan              exclusive prefix sum of the W*B counters
-//   scatter           thread per term: term index (+sign bit) written into its bucket's segment
+//   digits            thread per term: signed radix-2^c digits, stored window-major as 16-bit sign|magnitude
+//   tile histogram    workgroup per (window, tile of 8192 terms): bucket counts in LDS, no global atomics
+//   tile prefix       thread per (window, bucket): running sum over the tiles, totals per bucket
+//   scan              exclusive prefix sum of the W*B totals
+//   scatter           workgroup per (window, tile): positions from LDS counters seeded with
+//                     offset[bucket] + prefix[tile][bucket]; term index (+sign bit) into its bucket's segment
 //   accumulate        thread per chunk of M consecutive entries of the bucket-sorted array: mixed additions of
 //                     the entries' affine-Niels points; buckets that lie inside the chunk are finished there,
 //                     the (at most two) buckets cut by the chunk's borders leave partial sums
@@ -31,8 +34,7 @@ msm_plan msm_make_plan(u64 n) {
     else if (n < 4096) c = 9;
     else if (n < 200000) c = 12;
     else if (n < 1500000) c = 14;
-    else if (n < 6000000) c = 15;
-    else c = 16;
+    else c = 15;                                     // a digit is kept in 15 bits + sign
     msm_plan p;
     p.c = c; p.W = (252 + c - 1) / c; p.B = 1u << (c - 1);          // recoded scalars are below 2^252
     u32 L = p.B / 4096; if (L < 1) L = 1;          // S = B/(64L) <= 64
@@ -46,13 +48,15 @@ msm_plan msm_make_plan(u64 n) {
 static constexpr u32 SCAN_TILE = 1024;       // counters per workgroup of the bucket-offset scan
 static constexpr u32 MERGE_SPAN_MAX = 8;     // a bucket cut into more chunks than this is reduced by a workgroup
 
+static constexpr u32 SORT_TILE = 8192;        // terms per workgroup of the counting sort
+static inline u64 msm_sort_tiles(u64 n) { return n ? (n + SORT_TILE - 1) / SORT_TILE : 1; }
 static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return (e + p.M - 1) / p.M + 1; }
 
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
     u64 nb = (u64)p.W * p.B, entries = n * p.W, chunks = msm_chunks(n, p);
     msm_ws_bytes b;
-    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.cursor = nb * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
-    b.chunk_bucket = 64;                       // unused slot kept for layout stability
+    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.tile_hist = nb * msm_sort_tiles(n) * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
+    b.digits = (entries ? entries : 1) * 2;
     b.chunk_sums = chunks * 2 * 128; b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
     b.segs = (u64)p.W * p.S * 2 * 128 + (nb / SCAN_TILE + 1) * 4; b.wins = (u64)p.W * 128;          // segs doubles as the scan's tile sums
     return b;
@@ -97,18 +101,49 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32
     }
 }
 
-__global__ void __launch_bounds__(256) k_msm_histogram(const u32 *__restrict__ scalars, u64 n, msm_plan p, u32 *__restrict__ hist) {
+// digits[w * n + i]: bit 15 = sign, bits 0..14 = magnitude (0 = no contribution)
+__global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 s[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
     msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
-        if (d != 0) { u32 a = d < 0 ? (u32)(-d) : (u32)d; atomicAdd(&hist[(u64)w * p.B + (a - 1)], 1u); }
+        u32 a = d < 0 ? (u32)(-d) : (u32)d;
+        digits[(u64)w * n + i] = (unsigned short)(a | (d < 0 ? 0x8000u : 0u));
     });
 }
+// workgroup (tile, window): counts of the tile's digits per bucket -> tile_hist[(w * tiles + tile) * B + b]
+__global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, u32 *__restrict__ tile_hist) {
+    extern __shared__ u32 cnt[];
+    const u32 tile = blockIdx.x, w = blockIdx.y;
+    for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    u64 lo = (u64)tile * SORT_TILE, hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 a = digits[(u64)w * n + k] & 0x7fffu;
+        if (a) atomicAdd(&cnt[a - 1], 1u);
+    }
+    __syncthreads();
+    u32 *out = tile_hist + ((u64)w * tiles + tile) * p.B;
+    for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) out[b] = cnt[b];
+}
+// thread per (window, bucket): tile_hist becomes the count of the earlier tiles, hist the bucket's total
+__global__ void __launch_bounds__(256) k_msm_tile_prefix(u32 *__restrict__ tile_hist, msm_plan p, u32 tiles, u32 *__restrict__ hist) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.W * p.B) return;
+    u32 w = g / p.B, b = g % p.B;
+    u32 run = 0;
+    for (u32 t = 0; t < tiles; t++) {
+        u64 idx = ((u64)w * tiles + t) * p.B + b;
+        u32 v = tile_hist[idx];
+        tile_hist[idx] = run;
+        run += v;
+    }
+    hist[g] = run;
+}
 
-// Exclusive scan of `count` counters into offsets[count + 1] (cursor = copy of offsets), two launches:
+// Exclusive scan of `count` counters into offsets[count + 1], two launches:
 // sums of 1024-counter tiles, then every tile adds the sums of the tiles before it to its local scan.
 __device__ __forceinline__ u32 block_sum_256(u32 v, u32 *lds /* 4 */) {
 #pragma unroll
@@ -128,8 +163,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32 *__restrict__ 
     u32 r = block_sum_256(v, lds);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = r;
 }
-__global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, u32 count, const u32 *__restrict__ tile_sums, u32 *__restrict__ offsets,
-                                                  u32 *__restrict__ cursor) {
+__global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, u32 count, const u32 *__restrict__ tile_sums, u32 *__restrict__ offsets) {
     __shared__ u32 lds[4];
     __shared__ u32 part[256];
     u32 t = threadIdx.x;
@@ -151,26 +185,30 @@ __global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, 
     u32 run = base + part[t] - sum;
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
-        if (i0 + k < count) { offsets[i0 + k] = run; cursor[i0 + k] = run; }
+        if (i0 + k < count) offsets[i0 + k] = run;
         run += v[k];
         if (i0 + k + 1 == count) offsets[count] = run;
     }
 }
 
-__global__ void __launch_bounds__(256) k_msm_scatter(const u32 *__restrict__ scalars, u64 n, msm_plan p, u32 *__restrict__ cursor,
-                                                     u32 *__restrict__ sorted, u64 sorted_cap) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 s[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
-    msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
-        if (d != 0) {
-            u32 a = d < 0 ? (u32)(-d) : (u32)d;
-            u32 pos = atomicAdd(&cursor[(u64)w * p.B + (a - 1)], 1u);
-            if (pos < sorted_cap) sorted[pos] = (u32)i | (d < 0 ? 0x80000000u : 0u);
+// workgroup (tile, window): LDS counters start at the tile's first position inside each bucket's segment
+__global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
+                                                     const u32 *__restrict__ offsets, u32 *__restrict__ sorted, u64 sorted_cap) {
+    extern __shared__ u32 cnt[];
+    const u32 tile = blockIdx.x, w = blockIdx.y;
+    const u32 *pre = tile_hist + ((u64)w * tiles + tile) * p.B;
+    const u32 *off = offsets + (u64)w * p.B;
+    for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = off[b] + pre[b];
+    __syncthreads();
+    u64 lo = (u64)tile * SORT_TILE, hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 d = digits[(u64)w * n + k];
+        u32 a = d & 0x7fffu;
+        if (a) {
+            u32 pos = atomicAdd(&cnt[a - 1], 1u);
+            if (pos < sorted_cap) sorted[pos] = (u32)k | ((d & 0x8000u) << 16);
         }
-    });
+    }
 }
 __device__ __forceinline__ ge ge_shfl_down(const ge &p, u32 delta) {
     ge r;
@@ -483,16 +521,19 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
     hipError_t e;
+    const u32 tiles = (u32)msm_sort_tiles(n), lds_bytes = p.B * 4;
+    unsigned short *digits = (unsigned short *)ws.digits;
     MARK("msm_histogram");
-    if ((e = hipMemsetAsync(ws.hist, 0, n_buckets * 4, st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(ws.big_list, 0, 4, st)) != hipSuccess) return e;
-    if (n) hipLaunchKernelGGL(k_msm_histogram, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.hist);
+    if (n) hipLaunchKernelGGL(k_msm_digits, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, digits);
+    hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
+    hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);
     MARK("msm_scan");
-    u32 tiles = (u32)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
-    hipLaunchKernelGGL(k_msm_scan, dim3(tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets, ws.cursor);
+    u32 scan_tiles = (u32)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
+    hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets);
     MARK("msm_scatter");
-    if (n) hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, ws.cursor, ws.sorted, sorted_cap);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap);
     MARK("msm_accumulate");
     hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, n, d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
                        ws.buckets, ws.chunk_sums);

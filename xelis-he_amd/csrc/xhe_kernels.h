@@ -17,9 +17,9 @@ struct msm_plan {
 msm_plan msm_make_plan(u64 n);
 // device pointers of one multiscalar multiplication's workspace (sizes: see msm_workspace_bytes)
 struct msm_ws {
-    u32 *hist, *offsets, *cursor, *sorted, *buckets, *chunk_bucket, *chunk_sums, *big_list, *segs, *wins;
+    u32 *hist, *offsets, *tile_hist, *sorted, *buckets, *digits, *chunk_sums, *big_list, *segs, *wins;
 };
-struct msm_ws_bytes { u64 hist, offsets, cursor, sorted, buckets, chunk_bucket, chunk_sums, big_list, segs, wins; };
+struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins; };
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
 // result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)

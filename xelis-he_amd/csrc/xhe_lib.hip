@@ -81,7 +81,7 @@ struct stage_timer {
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
 };
 
-struct msm_workspace { dev_buf hist, offsets, cursor, sorted, buckets, chunk_bucket, chunk_sums, big_list, segs, wins; };
+struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins; };
 
 struct xhe_ctx {
     int device = 0;
@@ -135,14 +135,15 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     msm_ws_bytes need = msm_workspace_bytes(n, p);
     HIPCHK(ctx, ws.hist.reserve(need.hist));
     HIPCHK(ctx, ws.offsets.reserve(need.offsets));
-    HIPCHK(ctx, ws.cursor.reserve(need.cursor));
+    HIPCHK(ctx, ws.tile_hist.reserve(need.tile_hist));
+    HIPCHK(ctx, ws.digits.reserve(need.digits));
     HIPCHK(ctx, ws.sorted.reserve(need.sorted));
     HIPCHK(ctx, ws.buckets.reserve(need.buckets));
     HIPCHK(ctx, ws.chunk_sums.reserve(need.chunk_sums));
     HIPCHK(ctx, ws.big_list.reserve(need.big_list));
     HIPCHK(ctx, ws.segs.reserve(need.segs));
     HIPCHK(ctx, ws.wins.reserve(need.wins));
-    msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.cursor.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), nullptr, ws.chunk_sums.as<u32>(),
+    msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.tile_hist.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), ws.digits.as<u32>(), ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
     HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, extra_point, extra_ready, timing ? timer_mark : nullptr, ctx));
     return 0;
@@ -227,7 +228,7 @@ void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
-    for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.cursor,
+    for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
