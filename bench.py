@@ -25,6 +25,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak
 
 
+def measured_traffic(txs, transfers):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this very
+    workload (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from inside this process):
+    (FETCH_SIZE + WRITE_SIZE) KiB as reported, no correction factor.  None when no matching summary is committed."""
+    import csv
+    import glob
+    total, found = 0.0, 0
+    for counter in ("fetch_size", "write_size"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%dtx.csv" % (counter, txs))))
+        if not files or transfers != 1:
+            return None
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if row["kernel"].endswith("k_msm_accumulate"):
+                    total += float(row["avg"]) * 1024.0
+                    found += 1
+    return int(total) if found == 2 else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +147,7 @@ def main():
     if acc_ms > 0:
         achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                    "traffic": None, "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": algo_bytes}
+                    "traffic": measured_traffic(args.txs, args.transfers), "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": algo_bytes}
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:

@@ -33,6 +33,8 @@ struct host_batch {
     std::vector<dev_cm> cms;
     std::vector<dev_xfer> xfers;
     std::vector<dev_dec> decs;             // decode list; point index = n_static + position
+    std::vector<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
+    std::vector<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
     std::vector<dev_op> ops;               // sorted by slot
     std::vector<dev_sig> sigs;
     std::vector<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
@@ -106,21 +108,26 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     hb.multisig_set_by.assign(lv.n_accounts, -1);
 
     // ---- point index allocation ----
-    auto new_point = [&](u64 off, u32 rp_tx) -> u32 { hb.decs.push_back({off}); hb.rp_dec_tx.push_back(rp_tx); return hb.n_static + (u32)hb.decs.size() - 1; };
+    auto new_point = [&](u64 off, u32 rp_tx, u32 early = 0) -> u32 {          // early: 1 = ledger scan input, 2 = key
+        if (early == 1) hb.early_decs.push_back((u32)hb.decs.size());
+        if (early == 2) hb.key_decs.push_back((u32)hb.decs.size());
+        hb.decs.push_back({off, early, 0u}); hb.rp_dec_tx.push_back(rp_tx);
+        return hb.n_static + (u32)hb.decs.size() - 1;
+    };
     std::unordered_map<u32, u32> account_pt;          // account idx -> point idx
     std::unordered_map<u64, u32> signer_pt;           // byte offset of a signer key -> point idx
     std::unordered_map<u32, u32> used_slot;           // ledger balance idx -> used-slot idx
     std::vector<u32> slot_pt;                         // used-slot idx -> point idx of initial C (D = +1)
     std::vector<std::vector<dev_op>> slot_ops;        // per used slot, in order
-    auto get_account_pt = [&](u32 a) { auto it = account_pt.find(a); if (it != account_pt.end()) return it->second; u32 p = new_point(hb.keys_base + 32ull * a, 0xffffffffu); account_pt[a] = p; return p; };
+    auto get_account_pt = [&](u32 a) { auto it = account_pt.find(a); if (it != account_pt.end()) return it->second; u32 p = new_point(hb.keys_base + 32ull * a, 0xffffffffu, 2); account_pt[a] = p; return p; };
     // returns used-slot idx; *fresh = true when this is the first touch
     auto touch_slot = [&](u32 bal_idx, bool *fresh) {
         auto it = used_slot.find(bal_idx);
         if (it != used_slot.end()) { *fresh = false; return it->second; }
         u32 u = (u32)slot_pt.size();
         used_slot[bal_idx] = u;
-        u32 p = new_point(hb.cts_base + 64ull * bal_idx, 0xffffffffu);
-        new_point(hb.cts_base + 64ull * bal_idx + 32, 0xffffffffu);
+        u32 p = new_point(hb.cts_base + 64ull * bal_idx, 0xffffffffu, 1);
+        new_point(hb.cts_base + 64ull * bal_idx + 32, 0xffffffffu, 1);
         slot_pt.push_back(p); hb.slot_of_used.push_back(bal_idx);
         slot_ops.emplace_back();
         dev_op init{}; init.slot = u; init.kind = 0; init.c_pt = p; init.d_pt = p + 1; init.emit = 0xffffffffu; init.first = 1;
@@ -176,7 +183,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         u32 src_acc = src_known ? acc_it->second : 0;
         if (!src_known) raise(i, errkey(ST_NONCE, 0, 0, XHE_ERR_STATE));
         else if (lv.account_nonces[src_acc] != t.nonce) raise(i, errkey(ST_NONCE, 0, 1, XHE_ERR_INVALID_NONCE));
-        d.src_pt = src_known ? get_account_pt(src_acc) : new_point(rec + t.pre_off + 1, 0xffffffffu);
+        d.src_pt = src_known ? get_account_pt(src_acc) : new_point(rec + t.pre_off + 1, 0xffffffffu, 2);
         if (!record_commitment_assets_ok(t)) raise(i, errkey(ST_ASSETS, 0, 0, XHE_ERR_FORMAT));
 
         // main signature over pre-image || multisig entries (verify.rs:253-256)
@@ -198,7 +205,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                     if (idx < cfg.signer_off.size()) {
                         u64 koff = cfg.signer_off[idx];
                         auto sp = signer_pt.find(koff);
-                        u32 kp = sp != signer_pt.end() ? sp->second : (signer_pt[koff] = new_point(koff, 0xffffffffu));
+                        u32 kp = sp != signer_pt.end() ? sp->second : (signer_pt[koff] = new_point(koff, 0xffffffffu, 2));
                         dev_sig s{}; s.tx = (u32)i; s.key_pt = kp; s.key_off = koff; s.msg_off = 0; s.msg_len = 32; s.hash_idx = d.hash_idx;
                         s.sig_off = rec + t.ms_off + 65ull * k + 1; s.err_key = errkey(ST_MULTISIG, k, 3, XHE_ERR_SIGNATURE);
                         s.key_err_key = errkey(ST_MULTISIG, k, 2, XHE_ERR_DECOMPRESSION);
@@ -213,7 +220,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         for (u32 k = 0; k < T; k++) {
             u64 o = rec + t.transfer_off[k];
             u64 po = rec + t.transfer_off[k] + t.transfer_len[k] - 160;
-            xf_pt[k] = new_point(o + 64, 0xffffffffu); new_point(o + 96, 0xffffffffu); new_point(o + 128, 0xffffffffu);
+            xf_pt[k] = new_point(o + 64, 0xffffffffu, 1); new_point(o + 96, 0xffffffffu, 1); new_point(o + 128, 0xffffffffu, 1);
             new_point(po, 0xffffffffu); new_point(po + 32, 0xffffffffu); new_point(po + 64, 0xffffffffu);
         }
         // commitments (verify.rs:296-341)

@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_final(const u32 *__restrict__ s
 
 
 void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 *pts_in, const u32 *gtab, u32 *thread_excl, u32 *block_tot, const u32 *slot_last_op,
-                        u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok, u32 n_slots,
-                        u32 *final_cts) {
+                        u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok) {
     if (!n_ops) return;
     u32 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot);
@@ -128,6 +127,8 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
     hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot, slot_last_op, slot_base, slot_final,
                        emit_incl);
     if (n_emit) hipLaunchKernelGGL(k_scan_emit, dim3(grid_for(2 * n_emit, 256)), dim3(256), 0, st, emit_incl, emit_slot, slot_base, n_emit, emit_pt_base, pts, ok);
+}
+void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts) {
     if (n_slots) hipLaunchKernelGGL(k_scan_final, dim3(grid_for(2 * n_slots, 256)), dim3(256), 0, st, slot_final, slot_base, n_slots, final_cts);
 }
 

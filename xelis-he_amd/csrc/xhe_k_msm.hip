@@ -516,7 +516,7 @@ void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, 
 }
 
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, const u32 *extra_point, hipEvent_t extra_ready, msm_mark_fn mark, void *mark_user) {
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user) {
 #define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
@@ -534,6 +534,8 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets);
     MARK("msm_scatter");
     hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap);
+    MARK("msm_wait_points");
+    for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
     MARK("msm_accumulate");
     hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, n, d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
                        ws.buckets, ws.chunk_sums);
@@ -544,8 +546,8 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets, p, ws.segs);
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
     MARK("msm_horner");
-    if (extra_ready && (e = hipStreamWaitEvent(st, extra_ready, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
+    if (deps.extra_ready && (e = hipStreamWaitEvent(st, deps.extra_ready, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, deps.extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
 #undef MARK
     return hipGetLastError();
 }

@@ -81,10 +81,14 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 
 
 // ---- decode ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, u32 n, u32 pt_base,
+// list != null: the first pass over the n listed entries (the points the ledger scan and the signatures
+// wait for); list == null: all n entries except those of the first pass
+__global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (list) i = list[i];
+    else if (decs[i].early) return;
     u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);
     ge p; bool good = ristretto_decode_words(p, w);
     ge_niels_store(pts + 32ull * (pt_base + i), ge_to_niels_affine(p));
@@ -169,8 +173,8 @@ void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pt
 void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab) {
     if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
-void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, u32 n, u32 pt_base, u32 *pts, u8 *ok) {
-    if (n) hipLaunchKernelGGL(k_decode_list, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, decs, n, pt_base, pts, ok);
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok) {
+    if (n) hipLaunchKernelGGL(k_decode_list, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok);
 }
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);

@@ -23,9 +23,14 @@ struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chu
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
 // result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)
-// extra_point (nullable): an XYZT point added to the sum before the identity test, valid once extra_ready (nullable) has fired
+// What the multiscalar multiplication waits for on other streams: the sort of the scalars needs none of it.
+struct msm_deps {
+    hipEvent_t points_ready[2] = {nullptr, nullptr};   // waited for before the first point is gathered
+    const u32 *extra_point = nullptr;                   // an XYZT point added to the sum before the identity test ...
+    hipEvent_t extra_ready = nullptr;                   // ... valid once this has fired
+};
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, const u32 *extra_point, hipEvent_t extra_ready, msm_mark_fn mark, void *mark_user);
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user);
 // Sum of scalars[j] * P_j over the static generators B, H, G_vec[nm_cap], H_vec[nm_cap] from 32 x 256 fixed-base tables laid out
 // for capacity table_cap: partial sums per workgroup, then one wave.  partials: ceil(32 (2 + 2 nm_cap) / 256) XYZT records; out: one.
 void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, u32 nm_cap, u32 table_cap, u32 *partials, u32 *out);
@@ -52,7 +57,7 @@ void launch_count_bad(hipStream_t st, const u8 *ok, u64 n, u32 *out);
 void launch_base_points(hipStream_t st, u32 *out);
 void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pts);
 void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab);
-void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, u32 n, u32 pt_base, u32 *pts, u8 *ok);
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok);
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
 void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp);
 // transcript, hashes, signatures
@@ -65,8 +70,9 @@ void launch_schnorr(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n,
 static constexpr u32 SCAN_K = 4;          // operations per thread
 static constexpr u32 SCAN_BLOCK = 128;    // threads per block
 void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 *pts_in, const u32 *gtab, u32 *thread_excl, u32 *block_tot, const u32 *slot_last_op,
-                        u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok, u32 n_slots,
-                        u32 *final_cts);
+                        u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok);
+// the slots' resulting ciphertexts as 64-byte encodings (read back by the caller, not by any kernel)
+void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts);
 // proof scalars
 static constexpr u32 RPC_SCALARS = 53;    // Montgomery-limb scalars in a transaction's range-proof context
 void launch_sigma_cm(hipStream_t st, const u8 *bytes, const dev_cm *cms, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point, u32 *gh);

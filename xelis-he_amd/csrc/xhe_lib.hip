@@ -86,8 +86,9 @@ struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits
 struct xhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // [0] point decode + ledger scan, [1] signatures, [2] static-generator scalars; default priority
-    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] first decode pass + ledger scan, [1] signatures, [2] static-generator scalars,
+                                                                  // [3] second decode pass; all at the default priority
+    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -108,13 +109,13 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs;
+    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed})
             b->release();
@@ -128,7 +129,7 @@ static void set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) ctx->erro
 static hipError_t timer_mark(void *user, const char *name) { xhe_ctx *ctx = (xhe_ctx *)user; return ctx->timer.mark(name, ctx->stream); }
 
 static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool want_encoding,
-                          bool timing, const u32 *extra_point = nullptr, hipEvent_t extra_ready = nullptr) {
+                          bool timing, const msm_deps &deps = msm_deps()) {
     msm_workspace &ws = ctx->msm;
     msm_plan p = msm_make_plan(n);
     if (n * p.W > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
@@ -145,7 +146,7 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.wins.reserve(need.wins));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.tile_hist.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), ws.digits.as<u32>(), ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
-    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, extra_point, extra_ready, timing ? timer_mark : nullptr, ctx));
+    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, timing ? timer_mark : nullptr, ctx));
     return 0;
 }
 
@@ -217,8 +218,8 @@ xhe_ctx *xhe_create(int device_id) {
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
-              hipStreamCreate(&ctx->side[2]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
+              hipStreamCreate(&ctx->side[2]) == hipSuccess && hipStreamCreate(&ctx->side[3]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -227,13 +228,13 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -341,7 +342,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     for (u32 lg = 0; lg < 16; lg++) { B->group_off[lg] = (u32)group_txs.size(); group_txs.insert(group_txs.end(), hb.lg_groups[lg].begin(), hb.lg_groups[lg].end()); }
     B->group_off[16] = (u32)group_txs.size();
 #define UP(buf, vec) do { hipError_t e_ = upload_vec(B->buf, vec, st); if (e_ != hipSuccess) { set_error(ctx, std::string("upload " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
-    UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
+    UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs);
     UP(tx_err0, hb.tx_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
@@ -456,30 +457,44 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *tx_err = B->tx_err.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
     const u32 *sd = B->seed.as<u32>();
 
-    // side stream 0: decode every point of the batch, then the ledger as a prefix sum
-    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1];
+    // Enqueue order = who gets wave slots first: the longest dependent chain (keys -> signatures), then the ledger
+    // scan's inputs, then the transcripts that head the main path, then the bulk of the point decoding.
+    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1], s3 = ctx->side[3];
     HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
-    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
-    HIPCHK(ctx, tm.open("decode", s0));
-    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), n_dec, hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.close(s0));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s0));
-    HIPCHK(ctx, tm.open("ledger_scan", s0));
-    launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
-                       B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok, n_slots,
-                       B->final_cts.as<u32>());
-    HIPCHK(ctx, tm.close(s0));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));
-    // side stream 1: signatures (need the decoded keys)
-    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_decoded, 0));
+    // side stream 1: public keys, then the signatures
+    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
     HIPCHK(ctx, tm.open("signatures", s1));
+    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s1));
     launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
     launch_schnorr(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(), B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.close(s1));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
-    // main stream: transcripts (over the compressed bytes only), then the proof scalars
+    // side stream 0: ledger and transfer ciphertexts, then the ledger as a prefix sum
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode_first", s0));
+    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close(s0));
+    HIPCHK(ctx, tm.open("ledger_scan", s0));
+    launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
+                       B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
+    HIPCHK(ctx, tm.close(s0));
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_decoded, 0));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // keys, ledger inputs and the senders' new ciphertexts are in place
+    // main stream: transcripts (over the compressed bytes only)
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, n_txs, B->tmpl.as<u32>(), B->segs.as<u32>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
+    // side stream 3: every other point of the batch
+    HIPCHK(ctx, hipStreamWaitEvent(s3, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode_rest", s3));
+    launch_decode_list(s3, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close(s3));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[3], s3));
+    // side stream 0 again: resulting ledger ciphertexts, point-validity errors (need every point)
+    if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_side_done[3], 0));
+    launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
     HIPCHK(ctx, tm.mark("sigma_scalars", st));
     launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
     launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
@@ -511,18 +526,16 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         HIPCHK(ctx, tm.close(ss));
         HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], ss));
     }
-    HIPCHK(ctx, tm.mark("join_points", st));
-    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[0], 0));
-    HIPCHK(ctx, tm.mark("point_errors", st));
-    launch_point_errors(st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipGetLastError());
     // merged multiscalar check: sigma terms + range-proof terms (+ static generators, unless their sum comes from the tables)
-    int32_t rc = use_tables ? msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.static_term_off, B->verdict.as<u32>() + 4, false, true, ctx->static_sum.as<u32>(),
-                                         ctx->ev_side_done[2])
-                            : msm_device(ctx, scalars, pts, term_point, hb.n_points, hb.n_terms, B->verdict.as<u32>() + 4, false, true);
+    msm_deps deps;
+    deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[3];
+    if (use_tables) { deps.extra_point = ctx->static_sum.as<u32>(); deps.extra_ready = ctx->ev_side_done[2]; }
+    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps);
     if (rc) return rc;
     HIPCHK(ctx, tm.mark("join_signatures", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_points_checked, 0));
     HIPCHK(ctx, tm.mark("verdict", st));
     launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
     HIPCHK(ctx, tm.mark("end", st));
