@@ -73,6 +73,11 @@ __device__ __forceinline__ ge_niels ge_to_niels_normalize(const ge &p) {
     return ge_to_niels_affine(a);
 }
 
+// Kernels of few, long-running wavefronts that sit on the critical path (hash chains, the Horner stage,
+// the bucket reduction) raise their wave priority so the SIMD arbiter issues them ahead of the wide
+// throughput kernels (point decoding) that run beside them on other streams.
+__device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
+
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace xhe

@@ -48,6 +48,9 @@ struct host_batch {
     std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
     std::vector<u32> segs;                 // per-transaction segment tables
     std::vector<u32> serial_txs;           // transactions whose transcript runs in the serial kernel
+    std::vector<u32> tr_list;              // the others, sorted by template, each template padded to whole tiles of 64 (0xffffffff)
+    std::vector<transcript_tile> tr_tiles; // one per 64 entries of tr_list
+    transcript_plan tr_plan;
     u32 n_static = 0, nm_cap = 0;
     u32 n_points = 0;                      // static + decoded + emitted
     u32 emit_base = 0, n_emit = 0;         // emitted ciphertext points (2 per commitment)
@@ -290,6 +293,37 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             }
         }
         if (lg > 15 || ((u64)64 * d.m != (1ull << lg))) { /* range-proof stage reports it */ }
+    }
+    // ---- transcript tiles: transactions grouped by template (first appearance order), 64 per tile ----
+    {
+        std::vector<u32> order;                       // template offsets in order of first appearance
+        std::unordered_map<u32, std::vector<u32>> by_tmpl;
+        for (u64 i = 0; i < n; i++) {
+            u32 to = hb.txs[i].tmpl_off;
+            if (to == TT_NONE) continue;
+            auto it = by_tmpl.find(to);
+            if (it == by_tmpl.end()) { order.push_back(to); it = by_tmpl.emplace(to, std::vector<u32>()).first; }
+            it->second.push_back((u32)i);
+        }
+        transcript_pass cur{0, 0, 0};
+        u64 cur_words = 0;
+        for (u32 to : order) {
+            const std::vector<u32> &v = by_tmpl[to];
+            const u32 n_blocks = hb.tmpl[to + TT_H_BLOCKS];
+            const u64 tile_words = 21ull * 64 * n_blocks;
+            for (size_t k = 0; k < v.size(); k += 64) {
+                if (cur.n_tiles && cur_words + tile_words > TRANSCRIPT_STREAM_CAP_WORDS) {
+                    hb.tr_plan.passes.push_back(cur);
+                    cur = {(u32)hb.tr_tiles.size(), 0, 0}; cur_words = 0;
+                }
+                hb.tr_tiles.push_back({cur_words, to, n_blocks});
+                for (size_t j = k; j < k + 64; j++) hb.tr_list.push_back(j < v.size() ? v[j] : 0xffffffffu);
+                cur.n_tiles++; cur.max_blocks = std::max(cur.max_blocks, n_blocks);
+                cur_words += tile_words;
+                hb.tr_plan.stream_words = std::max(hb.tr_plan.stream_words, cur_words);
+            }
+        }
+        if (cur.n_tiles) hb.tr_plan.passes.push_back(cur);
     }
     hb.n_chal = chal;
     hb.static_term_off = term;

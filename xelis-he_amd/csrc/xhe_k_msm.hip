@@ -18,11 +18,12 @@
 //   reduce            wave per (window, 64*L buckets): running sums per lane, then lane-weighted sums
 //                     with wavefront shuffles
 //   window combine    wave per window over the segment partials (same shuffle scheme)
-//   horner            the 253 doublings over the window sums, compress, identity test
+//   horner            the 252 doublings over the window sums on one quad of lanes, compress, identity test
 // Points come in as 128-byte affine-Niels records (xhe_ge.h), scalars as canonical 32-byte values.
 // The work per thread of the accumulate stage is M additions whatever the distribution of the digits.
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
+#include "xhe_quad.h"
 
 namespace xhe {
 
@@ -349,6 +350,7 @@ __device__ __forceinline__ ge wave_weighted_sum(const ge &T, const ge &U, u32 lo
 // one wave per (window, segment of 64*L buckets): writes T (plain sum) and V (sum weighted by the
 // position inside the segment, 1-based) to seg_out[(w*S + s)*2 + {0,1}]
 __global__ void __launch_bounds__(64) k_msm_reduce_segments(const u32 *__restrict__ bucket_sums, msm_plan p, u32 *__restrict__ seg_out) {
+    wave_priority_high();
     u32 w = blockIdx.x / p.S, s = blockIdx.x % p.S;
     u32 lane = threadIdx.x;
     u32 base = s * 64 * p.L + lane * p.L;             // first bucket index (0-based) of this lane
@@ -370,6 +372,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const u32 *__restric
 
 // one wave per window over its S <= 64 segments: window sum = sum_s V_s + 64 L * sum_s s * T_s
 __global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict__ seg, msm_plan p, u32 *__restrict__ win_out) {
+    wave_priority_high();
     u32 w = blockIdx.x, lane = threadIdx.x;
     ge T = ge_identity(), V = ge_identity();
     if (lane < p.S) {
@@ -382,76 +385,25 @@ __global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict
     if (lane == 0) ge_store(win_out + 32ull * w, R);
 }
 
-// ---- four waves sharing one point computation --------------------------------------------------------
-// The 252 doublings of the Horner stage are one dependent chain; a lone wave issues one field product
-// after the other (about 1.5 k cycles each, eight per doubling).  Here the four waves of a 256-thread
-// workgroup each compute one of the four independent products of a phase and trade results through LDS,
-// so a doubling costs two products plus two barriers.  Every lane of a wave holds the same values.
-struct coop_exchange { u32 w[2][4][10]; };
-__device__ __forceinline__ void coop_put(u32 *slot, const fe &v) {
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) slot[i] = v.v[i];
-    }
-}
-__device__ __forceinline__ fe coop_get(const u32 *slot) {
-    fe r;
-#pragma unroll
-    for (int i = 0; i < 10; i++) r.v[i] = slot[i];
-    return r;
-}
-template <int ME, int MF, int MG, int MH>
-__device__ __forceinline__ ge coop_from_completed(const fe_t<ME> &E, const fe_t<MF> &F, const fe_t<MG> &G, const fe_t<MH> &H, u32 role, coop_exchange &x) {
-    fe mine;
-    if (role == 0) mine = fe_mul(E, F); else if (role == 1) mine = fe_mul(G, H); else if (role == 2) mine = fe_mul(F, G); else mine = fe_mul(E, H);
-    coop_put(x.w[1][role], mine);
-    __syncthreads();
-    ge r;
-    r.X = coop_get(x.w[1][0]); r.Y = coop_get(x.w[1][1]); r.Z = coop_get(x.w[1][2]); r.T = coop_get(x.w[1][3]);
-    return r;
-}
-__device__ __forceinline__ ge coop_double(const ge &p, u32 role, coop_exchange &x) {
-    fe mine;
-    if (role == 0) mine = fe_sq(p.X); else if (role == 1) mine = fe_sq(p.Y); else if (role == 2) mine = fe_sq(p.Z); else mine = fe_sq(fe_add(p.X, p.Y));
-    coop_put(x.w[0][role], mine);
-    __syncthreads();
-    fe A = coop_get(x.w[0][0]), B = coop_get(x.w[0][1]), ZZ = coop_get(x.w[0][2]), S = coop_get(x.w[0][3]);
-    auto C = fe_add(ZZ, ZZ);
-    auto H = fe_add(A, B);
-    auto E = fe_sub(S, H);
-    auto G = fe_sub(B, A);
-    fe F = fe_reduce(fe_sub(C, G));
-    return coop_from_completed(E, F, G, H, role, x);
-}
-__device__ __forceinline__ ge coop_add(const ge &p, const ge &q, u32 role, coop_exchange &x) {
-    fe mine;
-    if (role == 0) mine = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
-    else if (role == 1) mine = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
-    else if (role == 2) mine = fe_mul(fe_mul(p.T, fe_c_d2()), q.T);
-    else mine = fe_mul(p.Z, q.Z);
-    coop_put(x.w[0][role], mine);
-    __syncthreads();
-    fe A = coop_get(x.w[0][0]), B = coop_get(x.w[0][1]), C = coop_get(x.w[0][2]), ZZ = coop_get(x.w[0][3]);
-    auto D = fe_add(ZZ, ZZ);
-    return coop_from_completed(fe_sub(B, A), fe_sub(D, C), fe_add(D, C), fe_add(B, A), role, x);
-}
-
-// Horner over the windows, most significant first, one workgroup of four waves; writes the identity flag
-// and, when out_words is not null, the compressed result
-__global__ void __launch_bounds__(256) k_msm_horner(const u32 *__restrict__ win, msm_plan p, const u32 *__restrict__ extra_point /*may be null*/,
-                                                    u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag) {
-    __shared__ coop_exchange x;
-    const u32 role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    ge R = ge_load(win + 32ull * (p.W - 1));
+// Horner over the windows, most significant first.  The 252 doublings are one dependent chain, so one quad
+// of lanes shares the point (xhe_quad.h): a doubling costs one squaring and one multiplication per lane.
+// Writes the identity flag and, when out_words is not null, the compressed result.
+__global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, msm_plan p, const u32 *__restrict__ extra_point /*may be null*/,
+                                                   u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag) {
+    wave_priority_high();
+    if (threadIdx.x >= 4) return;
+    const u32 role = qd_role();
+    qd_point R = qd_load(win + 32ull * (p.W - 1), role);
     for (int w = (int)p.W - 2; w >= 0; w--) {
-        for (u32 k = 0; k < p.c; k++) R = coop_double(R, role, x);
-        R = coop_add(R, ge_load(win + 32ull * w), role, x);
+#pragma unroll 1
+        for (u32 k = 0; k < p.c; k++) R = qd_double(R, role);
+        R = qd_add(R, qd_load(win + 32ull * w, role), role);
     }
-    if (extra_point) R = coop_add(R, ge_load(extra_point), role, x);
-    if (role != 0) return;
-    bool ident = ge_ristretto_is_identity(R);
+    if (extra_point) R = qd_add(R, qd_load(extra_point, role), role);
+    ge full = qd_gather(R);
+    bool ident = ge_ristretto_is_identity(full);
     if (out_words) {
-        u32 enc[8]; ristretto_encode_words(enc, R);
+        u32 enc[8]; ristretto_encode_words(enc, full);
         if (threadIdx.x == 0) for (int i = 0; i < 8; i++) out_words[i] = enc[i];
     }
     if (threadIdx.x == 0) out_flag[0] = ident ? 1u : 0u;
@@ -547,7 +499,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
     MARK("msm_horner");
     if (deps.extra_ready && (e = hipStreamWaitEvent(st, deps.extra_ready, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(256), 0, st, ws.wins, p, deps.extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins, p, deps.extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
 #undef MARK
     return hipGetLastError();
 }

@@ -81,18 +81,20 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 
 
 // ---- decode ----------------------------------------------------------------------------------------
+static constexpr u32 DECODE_MAX_BLOCKS = 512;
 // list != null: the first pass over the n listed entries (the points the ledger scan and the signatures
 // wait for); list == null: all n entries except those of the first pass
 __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (list) i = list[i];
-    else if (decs[i].early) return;
-    u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);
-    ge p; bool good = ristretto_decode_words(p, w);
-    ge_niels_store(pts + 32ull * (pt_base + i), ge_to_niels_affine(p));
-    ok[pt_base + i] = good ? 1 : 0;
+    for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+        u32 i = g;
+        if (list) i = list[g];
+        else if (decs[g].early) continue;
+        u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);
+        ge p; bool good = ristretto_decode_words(p, w);
+        ge_niels_store(pts + 32ull * (pt_base + i), ge_to_niels_affine(p));
+        ok[pt_base + i] = good ? 1 : 0;
+    }
 }
 
 
@@ -174,7 +176,10 @@ void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases
     if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok) {
-    if (n) hipLaunchKernelGGL(k_decode_list, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok);
+    // at most two wavefronts per SIMD (512 workgroups of four on 256 CUs): the decode is the widest kernel of a verification and
+    // runs beside the critical path, whose few long-running wavefronts must find free slots the moment they are launched
+    u32 blocks = grid_for(n, 256);
+    if (n) hipLaunchKernelGGL(k_decode_list, dim3(blocks < DECODE_MAX_BLOCKS ? blocks : DECODE_MAX_BLOCKS), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok);
 }
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, co
                                                 const dev_xfer *__restrict__ xfers, u32 n_txs, const u32 *__restrict__ chal, const u32 *__restrict__ seed,
                                                 u32 *__restrict__ scalars, u32 *__restrict__ term_point, u32 *__restrict__ rp_ctx, u32 *__restrict__ gh,
                                                 u32 *__restrict__ rp_err) {
+    wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_txs) return;
     const dev_tx d = txs[i];

@@ -7,6 +7,7 @@ namespace xhe {
 __global__ void __launch_bounds__(64) k_schnorr(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u32 *__restrict__ pts,
                                                 const u8 *__restrict__ ok, const u32 *__restrict__ htab, const u8 *__restrict__ ms_hash,
                                                 u32 *__restrict__ tx_err) {
+    wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const dev_sig sg = sigs[i];

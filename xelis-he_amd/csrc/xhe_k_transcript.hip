@@ -1,4 +1,4 @@
-// Merlin transcript of every transaction (thread per transaction) and BLAKE3 of multisig pre-images.
+// Merlin transcript of every transaction and BLAKE3 of multisig pre-images.
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_transcript_template.h"
@@ -100,59 +100,22 @@ __global__ void __launch_bounds__(64) k_transcript_serial(const u8 *__restrict__
 }
 
 
-// ---- template transcript: 25 lanes hold the Keccak state of one transaction ---------------------------
-// Lane l = x + 5y of a 32-lane group holds state word A[x][y]; theta, pi and chi become lane shuffles
-// inside the group, rho a per-lane rotate.  Two transactions share a wavefront.  The transcript itself
-// is data: per block of 168 bytes a list of byte descriptors (xhe_transcript_template.h), so absorbing is
-// a gather and no lane interprets STROBE.
-struct keccak_lane_consts {
-    int col[4];        // the other four lanes of this lane's column
-    int xm1, xp1;      // lanes holding columns x-1 and x+1 (any row)
-    int pi_src;        // lane whose rotated word lands here
-    int x1, x2;        // lanes x+1, x+2 of this lane's row
-    u32 rot;           // rho offset of this lane's own word
-};
-__device__ __forceinline__ keccak_lane_consts keccak_lane_setup(u32 l) {
-    keccak_lane_consts k;
-    if (l >= 25) { for (int i = 0; i < 4; i++) k.col[i] = (int)l; k.xm1 = k.xp1 = k.pi_src = k.x1 = k.x2 = (int)l; k.rot = 0; return k; }
-    u32 x = l % 5, y = l / 5;
-    for (u32 i = 0; i < 4; i++) k.col[i] = (int)(x + 5 * ((y + 1 + i) % 5));
-    k.xm1 = (int)((x + 4) % 5 + 5 * y); k.xp1 = (int)((x + 1) % 5 + 5 * y);
-    k.pi_src = (int)((x + 3 * y) % 5 + 5 * x);                  // B[y][2x+3y] = rot(A[x][y]) solved for the source
-    k.x1 = (int)((x + 1) % 5 + 5 * y); k.x2 = (int)((x + 2) % 5 + 5 * y);
-    const u8 RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    k.rot = RHO[l];
-    return k;
-}
-__device__ __forceinline__ u64 shfl64_group(u64 v, int src) {
-    u32 lo = (u32)__shfl((int)(u32)v, src, 32), hi = (u32)__shfl((int)(u32)(v >> 32), src, 32);
-    return (u64)lo | ((u64)hi << 32);
-}
-__device__ __forceinline__ u64 keccak_f1600_lanes(u64 a, const keccak_lane_consts &k, u32 l) {
-    const u64 RC[24] = {
-        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-#pragma unroll 2
-    for (int round = 0; round < 24; round++) {
-        u64 c = a ^ shfl64_group(a, k.col[0]) ^ shfl64_group(a, k.col[1]) ^ shfl64_group(a, k.col[2]) ^ shfl64_group(a, k.col[3]);
-        u64 d = shfl64_group(c, k.xm1) ^ rotl64(shfl64_group(c, k.xp1), 1);
-        a ^= d;
-        u64 r = (a << k.rot) | (a >> ((64 - k.rot) & 63));
-        u64 b = shfl64_group(r, k.pi_src);
-        u64 b1 = shfl64_group(b, k.x1), b2 = shfl64_group(b, k.x2);
-        a = b ^ (~b1 & b2);
-        if (l == 0) a ^= RC[round];
-    }
-    return a;
-}
+// ---- template transcript: staged byte stream, then one thread per transaction --------------------------
+// The transcript itself is data: per block of 168 bytes a list of byte descriptors
+// (xhe_transcript_template.h), so absorbing is a gather and no thread interprets STROBE.  Two kernels:
+//   k_transcript_stage   gathers every 8-byte state word of every block of every transaction (massively
+//                        parallel, byte loads from the unaligned records) into a stream laid out
+//                        [tile of 64 transactions][block][word][lane], and runs the all-zero-encoding checks;
+//   k_transcript_keccak  one thread per transaction with the 25 state words in registers: per block 21
+//                        coalesced 8-byte loads, XOR, Keccak-f[1600]; a challenge is squeezed where the
+//                        template says so.
+// Transactions are taken from a list sorted by template and padded per template to whole tiles, so a
+// wavefront runs one template and its control flow is uniform.
+static constexpr u32 TR_PAD = 0xffffffffu;
+static constexpr u32 STAGE_ROWS = 7;         // words of a block handled per pass of a 448-thread workgroup
 
-// the eight bytes of block `b` that belong to lane l (l < 21), assembled from the descriptors
+// the eight bytes of state word l (< 21) of block b, assembled from the descriptors
 __device__ __forceinline__ u64 transcript_gather(const u32 *__restrict__ desc, u32 b, u32 l, const u8 *__restrict__ rec, const u32 *__restrict__ seg) {
-    if (l >= 21) return 0;
     const uint4 *dp = (const uint4 *)(desc + (u64)b * TT_BLOCK_BYTES + 8 * l);
     uint4 d0 = dp[0], d1 = dp[1];
     u32 ds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -168,43 +131,117 @@ __device__ __forceinline__ u64 transcript_gather(const u32 *__restrict__ desc, u
     return word;
 }
 
-__global__ void __launch_bounds__(256) k_transcript(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl,
-                                                    const u32 *__restrict__ segs, u32 n_txs, u32 *__restrict__ chal, u32 *__restrict__ tx_err,
-                                                    u32 *__restrict__ rp_err) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 i = g >> 5, l = g & 31;
-    if (i >= n_txs) return;
-    const u32 tmpl_off = txs[i].tmpl_off;
-    if (tmpl_off == TT_NONE) return;
+__global__ void __launch_bounds__(64 * STAGE_ROWS) k_transcript_stage(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl,
+                                                                      const u32 *__restrict__ segs, const u32 *__restrict__ list, const transcript_tile *__restrict__ tiles,
+                                                                      u32 tile0, u64 *__restrict__ stream, u32 *__restrict__ tx_err, u32 *__restrict__ rp_err) {
+    const u32 tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const transcript_tile tt = tiles[tile];
+    const u32 i = list[64ull * tile + lane];
+    if (i == TR_PAD) return;
     const u8 *rec = bytes + txs[i].rec;
     const u32 *seg = segs + txs[i].seg_off;
+    const u32 *hdr = tmpl + tt.tmpl_off;
+    const u32 n_blocks = hdr[TT_H_BLOCKS], n_checks = hdr[TT_H_CHECKS];
+    const u32 *checks = hdr + TT_H_WORDS + n_blocks, *desc = tmpl + hdr[TT_H_DESC];
+    if (blockIdx.y == 0) {
+        // encodings that must not be all-zero (validate_and_append_point)
+        for (u32 c = row; c < n_checks; c += STAGE_ROWS) {
+            u32 ds = checks[2 * c], key = checks[2 * c + 1];
+            const u8 *p = rec + seg[ds >> 16] + (ds & 0xffffu);
+            u32 acc = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) acc |= p[k];
+            if (!acc) { if (key) raise_err(tx_err, i, key); else rp_err[i] = 1; }
+        }
+    }
+    u64 *out = stream + tt.stream_off + lane;
+    for (u32 b = blockIdx.y; b < n_blocks; b += gridDim.y) {
+#pragma unroll
+        for (u32 w = row; w < 21; w += STAGE_ROWS) out[(u64)(b * 21 + w) * 64] = transcript_gather(desc, b, w, rec, seg);
+    }
+}
+
+// 64-bit rotate left by a constant as two v_alignbit_b32 (the generic shift/or form costs two 64-bit shifts and two ORs)
+template <int N>
+__device__ __forceinline__ u64 rotl64c(u64 x) {
+    static_assert(N > 0 && N < 64, "rotation count");
+    u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if (N >= 32) { u32 t = lo; lo = hi; hi = t; }
+    constexpr int R = N & 31;
+    if (R == 0) return (u64)lo | ((u64)hi << 32);
+    u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+    return (u64)nl | ((u64)nh << 32);
+}
+// Keccak-f[1600] on 25 words that stay in registers (every index is a compile-time constant)
+__device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
+    const u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+        u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+        u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+        u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+        u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        u64 d0 = c4 ^ rotl64c<1>(c1), d1 = c0 ^ rotl64c<1>(c2), d2 = c1 ^ rotl64c<1>(c3), d3 = c2 ^ rotl64c<1>(c4), d4 = c3 ^ rotl64c<1>(c0);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) { a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4; }
+        u64 b[25];
+        b[0] = a[0];
+        b[10] = rotl64c<1>(a[1]);   b[20] = rotl64c<62>(a[2]);  b[5] = rotl64c<28>(a[3]);   b[15] = rotl64c<27>(a[4]);
+        b[16] = rotl64c<36>(a[5]);  b[1] = rotl64c<44>(a[6]);   b[11] = rotl64c<6>(a[7]);   b[21] = rotl64c<55>(a[8]);  b[6] = rotl64c<20>(a[9]);
+        b[7] = rotl64c<3>(a[10]);   b[17] = rotl64c<10>(a[11]); b[2] = rotl64c<43>(a[12]);  b[12] = rotl64c<25>(a[13]); b[22] = rotl64c<39>(a[14]);
+        b[23] = rotl64c<41>(a[15]); b[8] = rotl64c<45>(a[16]);  b[18] = rotl64c<15>(a[17]); b[3] = rotl64c<21>(a[18]);  b[13] = rotl64c<8>(a[19]);
+        b[14] = rotl64c<18>(a[20]); b[24] = rotl64c<2>(a[21]);  b[9] = rotl64c<61>(a[22]);  b[19] = rotl64c<56>(a[23]); b[4] = rotl64c<14>(a[24]);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
+            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
+            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
+            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
+            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+        }
+        a[0] ^= RC[round];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_transcript_keccak(const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl, const u32 *__restrict__ list,
+                                                          const transcript_tile *__restrict__ tiles, u32 tile0, const u64 *__restrict__ stream, u32 *__restrict__ chal) {
+    wave_priority_high();
+    const u32 tile = tile0 + blockIdx.x, lane = threadIdx.x;
+    const u32 tmpl_off = __builtin_amdgcn_readfirstlane(tiles[tile].tmpl_off);
+    const u64 stream_off = tiles[tile].stream_off;
+    const u32 i = list[64ull * tile + lane];
+    if (i == TR_PAD) return;
     const u32 chal_off = txs[i].chal_off;
     const u32 *hdr = tmpl + tmpl_off;
-    const u32 n_blocks = hdr[TT_H_BLOCKS], n_checks = hdr[TT_H_CHECKS];
-    const u32 *chal_after = hdr + TT_H_WORDS, *checks = chal_after + n_blocks, *desc = tmpl + hdr[TT_H_DESC];
-    // encodings that must not be all-zero
-    for (u32 c = l; c < n_checks; c += 32) {
-        u32 ds = checks[2 * c], key = checks[2 * c + 1];
-        const u8 *p = rec + seg[ds >> 16] + (ds & 0xffffu);
-        u32 acc = 0;
-        for (int k = 0; k < 32; k++) acc |= p[k];
-        if (!acc) { if (key) raise_err(tx_err, i, key); else rp_err[i] = 1; }
-    }
-    const keccak_lane_consts kc = keccak_lane_setup(l);
-    u64 a = 0;
-    u64 word = transcript_gather(desc, 0, l, rec, seg);
+    const u32 n_blocks = __builtin_amdgcn_readfirstlane(hdr[TT_H_BLOCKS]);
+    const u32 *chal_after = hdr + TT_H_WORDS;
+    const u64 *in = stream + stream_off + lane;
+    u64 a[25], nx[21];
+#pragma unroll
+    for (int w = 0; w < 25; w++) a[w] = 0;
+#pragma unroll
+    for (int w = 0; w < 21; w++) nx[w] = in[64 * w];
     for (u32 b = 0; b < n_blocks; b++) {
-        a ^= word;
-        if (b + 1 < n_blocks) word = transcript_gather(desc, b + 1, l, rec, seg);     // in flight during the permutation
-        a = keccak_f1600_lanes(a, kc, l);
-        u32 ci = chal_after[b];
+#pragma unroll
+        for (int w = 0; w < 21; w++) a[w] ^= nx[w];
+        if (b + 1 < n_blocks) {                        // in flight during the permutation
+#pragma unroll
+            for (int w = 0; w < 21; w++) nx[w] = in[(u64)((b + 1) * 21 + w) * 64];
+        }
+        keccak_f1600_regs(a);
+        u32 ci = __builtin_amdgcn_readfirstlane(chal_after[b]);
         if (ci != TT_NONE) {
             u32 w[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { w[2 * k] = (u32)__shfl((int)(u32)a, k, 32); w[2 * k + 1] = (u32)__shfl((int)(u32)(a >> 32), k, 32); }
-            sc x = sc_from_wide_words(w);
-            if (l == 0) store_scalar_words(chal + 8ull * (chal_off + ci), x);
-            if (l < 8) a = 0;
+            for (int k = 0; k < 8; k++) { w[2 * k] = (u32)a[k]; w[2 * k + 1] = (u32)(a[k] >> 32); a[k] = 0; }
+            store_scalar_words(chal + 8ull * (chal_off + ci), sc_from_wide_words(w));
         }
     }
 }
@@ -222,9 +259,14 @@ __global__ void __launch_bounds__(64) k_blake3_preimages(const u8 *__restrict__ 
 }
 
 
-void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *tmpl, const u32 *segs,
-                       const u32 *serial_list, u32 n_serial, u32 *chal, u32 *tx_err, u32 *rp_err) {
-    if (n_txs > n_serial) hipLaunchKernelGGL(k_transcript, dim3(grid_for(32ull * n_txs, 256)), dim3(256), 0, st, bytes, txs, tmpl, segs, n_txs, chal, tx_err, rp_err);
+void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, const u32 *tmpl, const u32 *segs,
+                       const transcript_plan &plan, const u32 *list, const transcript_tile *tiles, u64 *stream, const u32 *serial_list, u32 n_serial, u32 *chal,
+                       u32 *tx_err, u32 *rp_err) {
+    for (const transcript_pass &ps : plan.passes) {
+        u32 gy = ps.max_blocks < 64 ? ps.max_blocks : 64;
+        hipLaunchKernelGGL(k_transcript_stage, dim3(ps.n_tiles, gy ? gy : 1), dim3(64 * STAGE_ROWS), 0, st, bytes, txs, tmpl, segs, list, tiles, ps.tile0, stream, tx_err, rp_err);
+        hipLaunchKernelGGL(k_transcript_keccak, dim3(ps.n_tiles), dim3(64), 0, st, txs, tmpl, list, tiles, ps.tile0, stream, chal);
+    }
     if (n_serial) hipLaunchKernelGGL(k_transcript_serial, dim3(grid_for(n_serial, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, serial_list, n_serial, chal, tx_err, rp_err);
 }
 void launch_blake3_preimages(hipStream_t st, const u8 *bytes, const dev_tx *txs, const u32 *hash_tx, u32 n, u8 *out) {

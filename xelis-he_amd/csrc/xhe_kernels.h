@@ -61,9 +61,12 @@ void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, co
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
 void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp);
 // transcript, hashes, signatures
-// tmpl/segs: transcript templates and per-transaction segment tables; serial_list: transactions without a template
-void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *tmpl, const u32 *segs,
-                       const u32 *serial_list, u32 n_serial, u32 *chal, u32 *tx_err, u32 *rp_err);
+// tmpl/segs: transcript templates and per-transaction segment tables; list/tiles: the transactions with a template, sorted by
+// template and padded to whole tiles; the stream buffer (plan.stream_words 8-byte words) is reused by the passes;
+// serial_list: transactions without a template
+void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, const u32 *tmpl, const u32 *segs,
+                       const transcript_plan &plan, const u32 *list, const transcript_tile *tiles, u64 *stream, const u32 *serial_list, u32 n_serial, u32 *chal,
+                       u32 *tx_err, u32 *rp_err);
 void launch_blake3_preimages(hipStream_t st, const u8 *bytes, const dev_tx *txs, const u32 *hash_tx, u32 n, u8 *out);
 void launch_schnorr(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u8 *ok, const u32 *htab, const u8 *ms_hash, u32 *tx_err);
 // ledger scan

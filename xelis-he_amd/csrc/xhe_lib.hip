@@ -3,6 +3,7 @@
 // (xhe_ingest.h); all field, group and hash arithmetic of the verification path runs in the kernels.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@ using namespace xhe;
     } while (0)
 
 static std::string g_create_error;
+static unsigned exp_flags() { const char *e = getenv("XHE_EXP"); return e ? (unsigned)atoi(e) : 0u; }
 
 struct dev_buf {
     void *p = nullptr; size_t cap = 0;
@@ -88,7 +90,7 @@ struct xhe_ctx {
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] first decode pass + ledger scan, [1] signatures, [2] static-generator scalars,
                                                                   // [3] second decode pass; all at the default priority
-    hipEvent_t ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_transcript = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -109,13 +111,13 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs;
+    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed})
             b->release();
@@ -219,7 +221,7 @@ xhe_ctx *xhe_create(int device_id) {
     ctx->device = device_id;
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
               hipStreamCreate(&ctx->side[2]) == hipSuccess && hipStreamCreate(&ctx->side[3]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
+    for (hipEvent_t *e : {&ctx->ev_transcript, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -233,7 +235,7 @@ void xhe_destroy(xhe_ctx *ctx) {
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_transcript, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
@@ -343,7 +345,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     B->group_off[16] = (u32)group_txs.size();
 #define UP(buf, vec) do { hipError_t e_ = upload_vec(B->buf, vec, st); if (e_ != hipSuccess) { set_error(ctx, std::string("upload " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
     UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
-    UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs);
+    UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
     UP(tx_err0, hb.tx_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
     u64 n_slots = hb.slot_of_used.size();
@@ -356,7 +358,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     RS(gh, 72ull * n_parts); RS(gh_sums, 72ull * 256); RS(rp_ctx, 36ull * RPC_SCALARS * hb.n_txs); RS(rp_acc, 72ull * hb.nm_cap);
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
-    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32);
+    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words);
     // partial column sums of the range-proof scalar matrix: one row per tile of transactions
     {
         u64 worst = 0;
@@ -461,8 +463,14 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     // scan's inputs, then the transcripts that head the main path, then the bulk of the point decoding.
     hipStream_t s0 = ctx->side[0], s1 = ctx->side[1], s3 = ctx->side[3];
     HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
+    // main stream: transcripts (over the compressed bytes only)
+    HIPCHK(ctx, tm.mark("transcript", st));
+    launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
+                      B->tr_stream.as<u64>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_transcript, st));
     // side stream 1: public keys, then the signatures
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
+    if (exp_flags() & 1) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_transcript, 0));
     HIPCHK(ctx, tm.open("signatures", s1));
     launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
     HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s1));
@@ -472,6 +480,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
     // side stream 0: ledger and transfer ciphertexts, then the ledger as a prefix sum
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
+    if (exp_flags() & 4) HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_transcript, 0));
     HIPCHK(ctx, tm.open("decode_first", s0));
     launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
     HIPCHK(ctx, tm.close(s0));
@@ -481,11 +490,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, tm.close(s0));
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_decoded, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // keys, ledger inputs and the senders' new ciphertexts are in place
-    // main stream: transcripts (over the compressed bytes only)
-    HIPCHK(ctx, tm.mark("transcript", st));
-    launch_transcript(st, bytes, txs, cms, xfers, n_txs, B->tmpl.as<u32>(), B->segs.as<u32>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
     // side stream 3: every other point of the batch
     HIPCHK(ctx, hipStreamWaitEvent(s3, ctx->ev_setup, 0));
+    if (exp_flags() & 2) HIPCHK(ctx, hipStreamWaitEvent(s3, ctx->ev_transcript, 0));
     HIPCHK(ctx, tm.open("decode_rest", s3));
     launch_decode_list(s3, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
     HIPCHK(ctx, tm.close(s3));

@@ -8,6 +8,7 @@
 // [7:0] error code.  Every kernel that detects a failure does atomicMin on the transaction's key.
 #pragma once
 #include <stdint.h>
+#include <vector>
 #include "xhe_fe.h"
 
 namespace xhe {
@@ -76,6 +77,15 @@ struct dev_op {
     u32 emit;                // 0xffffffff, or index into the emitted ciphertext list (sender's new balance)
     u32 first;               // 1: first operation of its slot (the initial balance)
 };
+
+// Transcript kernels: transactions sorted by template and cut into tiles of 64 (one wavefront); the staged
+// byte stream of a tile starts at stream_off (in 8-byte words) inside the pass's buffer and holds
+// [block][state word 0..20][lane] for the n_blocks blocks of the tile's template.
+struct transcript_tile { u64 stream_off; u32 tmpl_off; u32 n_blocks; };
+// host side: consecutive tiles that share one stream buffer of stream_words words (the passes reuse it)
+struct transcript_pass { u32 tile0, n_tiles, max_blocks; };
+struct transcript_plan { std::vector<transcript_pass> passes; u64 stream_words = 0; };
+static constexpr u64 TRANSCRIPT_STREAM_CAP_WORDS = 1ull << 27;      // 1 GiB per pass
 
 // one per signature to verify
 struct dev_sig {
