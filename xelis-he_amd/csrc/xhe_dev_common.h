@@ -78,6 +78,55 @@ __device__ __forceinline__ ge_niels ge_to_niels_normalize(const ge &p) {
 // throughput kernels (point decoding) that run beside them on other streams.
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 
+// 64-bit rotate left by a constant as two v_alignbit_b32 (the generic shift/or form costs two 64-bit shifts and two ORs)
+template <int N>
+__device__ __forceinline__ u64 rotl64c(u64 x) {
+    static_assert(N > 0 && N < 64, "rotation count");
+    u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if (N >= 32) { u32 t = lo; lo = hi; hi = t; }
+    constexpr int R = N & 31;
+    if (R == 0) return (u64)lo | ((u64)hi << 32);
+    u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+    return (u64)nl | ((u64)nh << 32);
+}
+// Keccak-f[1600] on 25 words that stay in registers (every index is a compile-time constant)
+__device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
+    const u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+        u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+        u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+        u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+        u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        u64 d0 = c4 ^ rotl64c<1>(c1), d1 = c0 ^ rotl64c<1>(c2), d2 = c1 ^ rotl64c<1>(c3), d3 = c2 ^ rotl64c<1>(c4), d4 = c3 ^ rotl64c<1>(c0);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) { a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4; }
+        u64 b[25];
+        b[0] = a[0];
+        b[10] = rotl64c<1>(a[1]);   b[20] = rotl64c<62>(a[2]);  b[5] = rotl64c<28>(a[3]);   b[15] = rotl64c<27>(a[4]);
+        b[16] = rotl64c<36>(a[5]);  b[1] = rotl64c<44>(a[6]);   b[11] = rotl64c<6>(a[7]);   b[21] = rotl64c<55>(a[8]);  b[6] = rotl64c<20>(a[9]);
+        b[7] = rotl64c<3>(a[10]);   b[17] = rotl64c<10>(a[11]); b[2] = rotl64c<43>(a[12]);  b[12] = rotl64c<25>(a[13]); b[22] = rotl64c<39>(a[14]);
+        b[23] = rotl64c<41>(a[15]); b[8] = rotl64c<45>(a[16]);  b[18] = rotl64c<15>(a[17]); b[3] = rotl64c<21>(a[18]);  b[13] = rotl64c<8>(a[19]);
+        b[14] = rotl64c<18>(a[20]); b[24] = rotl64c<2>(a[21]);  b[9] = rotl64c<61>(a[22]);  b[19] = rotl64c<56>(a[23]); b[4] = rotl64c<14>(a[24]);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
+            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
+            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
+            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
+            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+        }
+        a[0] ^= RC[round];
+    }
+}
+
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace xhe

@@ -1,58 +1,198 @@
-// Schnorr signature verification (src/elgamal.rs:38-65), thread per signature.
+// Schnorr signature verification (/root/reference/src/elgamal.rs:38-65): accept iff
+// e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Three kernels, the first two independent of each other:
+//   k_sig_absorb   thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
+//                  held in registers (the bulk of the hashing: 19 of the 20 permutations for a one-transfer
+//                  transaction) -- needs no point, so it runs beside the point kernel;
+//   k_sig_point    four lanes per signature (xhe_quad.h): s*H from the 8-bit fixed-base table, e*P with signed
+//                  4-bit windows over a table of 0..8 P kept in LDS, R = s*H - e*P as an XYZT record;
+//   k_sig_final    thread per signature: encodes R, absorbs the message tail || enc(R) || padding, squeezes,
+//                  reduces mod l and compares with e.
+// A multisig co-signature hashes the 32-byte BLAKE3 digest of the pre-image instead of the message
+// (/root/reference/src/tx/verify.rs:259-292): it has no whole block before R, so only the last kernel hashes.
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
+#include "xhe_quad.h"
 
 namespace xhe {
 
-__global__ void __launch_bounds__(64) k_schnorr(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u32 *__restrict__ pts,
-                                                const u8 *__restrict__ ok, const u32 *__restrict__ htab, const u8 *__restrict__ ms_hash,
-                                                u32 *__restrict__ tx_err) {
+static constexpr u32 SIG_RATE_WORDS = 9;      // SHA3-512: 72-byte rate
+
+// byte j of pk || msg (msg = the digest for a co-signature)
+struct sig_stream {
+    const u8 *key, *msg;
+    __device__ __forceinline__ u8 at(u32 j) const { return j < 32 ? key[j] : msg[j - 32]; }
+};
+__device__ __forceinline__ sig_stream sig_stream_of(const dev_sig &sg, const u8 *__restrict__ bytes, const u8 *__restrict__ ms_hash) {
+    sig_stream s;
+    s.key = bytes + sg.key_off;
+    s.msg = sg.hash_idx != 0xffffffffu ? ms_hash + 32ull * sg.hash_idx : bytes + sg.msg_off;
+    return s;
+}
+__device__ __forceinline__ u32 sig_whole_blocks(const dev_sig &sg) { return sg.hash_idx != 0xffffffffu ? 0u : (32u + sg.msg_len) / 72u; }
+
+// state[w * n + i]: word w of signature i's sponge after its whole blocks
+__global__ void __launch_bounds__(64) k_sig_absorb(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, u64 *__restrict__ state) {
     wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const dev_sig sg = sigs[i];
-    if (!ok[sg.key_pt]) { if (sg.key_err_key) raise_err(tx_err, sg.tx, sg.key_err_key); return; }
+    const u32 nb = sig_whole_blocks(sg);
+    const u8 *key = bytes + sg.key_off, *msg = bytes + sg.msg_off;
+    u64 a[25];
+#pragma unroll
+    for (int w = 0; w < 25; w++) a[w] = 0;
+    for (u32 b = 0; b < nb; b++) {
+        // block 0 starts with the 32 key bytes; word w of block b holds the message bytes from 72 b + 8 w - 32
+        const u8 *src = msg + 72ull * b;
+#pragma unroll
+        for (int w = 0; w < (int)SIG_RATE_WORDS; w++) {
+            const u8 *p = (b == 0 && w < 4) ? key + 8 * w : src + 8 * w - 32;
+            u64 word = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) word |= (u64)p[k] << (8 * k);
+            a[w] ^= word;
+        }
+        keccak_f1600_regs(a);
+    }
+#pragma unroll
+    for (int w = 0; w < 25; w++) state[(u64)w * n + i] = a[w];
+}
+
+// ---- R = s*H - e*P on a quad of lanes ---------------------------------------------------------------
+// this lane's multiplicand of a "cached" point (Y - X, Y + X, Z, 2d T), all of magnitude 1
+__device__ __forceinline__ fe qd_to_cached(const qd_point &p, u32 role) {
+    fe c = fe_reduce(qd_add_operand(p.c, role));
+    fe t = fe_mul(c, fe_c_d2());
+    fe out;
+#pragma unroll
+    for (int i = 0; i < 10; i++) out.v[i] = role == 3 ? t.v[i] : c.v[i];
+    return out;
+}
+// p + q (or p - q) with q given by this lane's cached multiplicand
+__device__ __forceinline__ qd_point qd_add_cached(const qd_point &p, const fe &cached, bool negative, u32 role) {
+    // the negated point swaps (Y - X) with (Y + X) and negates 2d T
+    fe neg = fe_negate(cached);
+    fe b;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        u32 swapped = qd_pull<XHE_QP(1, 0, 2, 3)>(cached.v[i]);
+        b.v[i] = negative ? (role == 3 ? neg.v[i] : swapped) : cached.v[i];
+    }
+    return qd_add_finish(fe_mul(qd_add_operand(p.c, role), b), role);
+}
+
+static constexpr u32 SIG_QUADS = 16;          // signatures per 64-thread workgroup
+
+__global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u32 *__restrict__ pts,
+                                                  const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
+    wave_priority_high();
+    __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
+    const u32 lane = threadIdx.x, role = lane & 3;
+    const u32 q = blockIdx.x * SIG_QUADS + (lane >> 2);
+    const u32 i = q < n ? q : n - 1;           // spare quads repeat the last signature and store nothing
+    const dev_sig sg = sigs[i];
     u32 sw[8], ew[8];
     load_words_unaligned(sw, bytes + sg.sig_off); load_words_unaligned(ew, bytes + sg.sig_off + 32);
-    // s * H from the fixed-base table (32 windows of 8 bits)
-    ge R = ge_identity();
+
+    // table of k * P, k = 0..8 (an undecodable key left the identity in pts[]; the last kernel reports it)
+    {
+        ge_niels pn = ge_niels_load(pts + 32ull * sg.key_pt);
+        qd_point P = qd_from_ge(ge_from_niels_affine(pn), role);
+        qd_point m[9];
+        m[0] = qd_identity(role); m[1] = P;
+        m[2] = qd_double(P, role); m[3] = qd_add(m[2], P, role); m[4] = qd_double(m[2], role); m[5] = qd_add(m[4], P, role);
+        m[6] = qd_double(m[3], role); m[7] = qd_add(m[6], P, role); m[8] = qd_double(m[4], role);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            fe c = qd_to_cached(m[k], role);
+#pragma unroll
+            for (int l = 0; l < 10; l++) tab[k][l][lane] = c.v[l];
+        }
+    }
+    // Q = e * P with signed radix-16 digits in [-8, 8], most significant first.  The carry into digit k depends on
+    // all lower digits, so the carries are worked out first, one bit per digit.
+    qd_point Q = qd_identity(role);
+    {
+        u64 carry_bits = 0;
+        u32 carry = 0;
+        for (u32 k = 0; k < 64; k++) {
+            carry_bits |= (u64)carry << k;
+            u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + carry;
+            carry = v > 8 ? 1u : 0u;
+        }
+#pragma unroll 1
+        for (int k = 63; k >= 0; k--) {
+            Q = qd_double(qd_double(qd_double(qd_double(Q, role), role), role), role);
+            u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + (u32)((carry_bits >> k) & 1);
+            bool negative = v > 8;
+            u32 mag = negative ? 16 - v : v;
+            fe c;
+#pragma unroll
+            for (int l = 0; l < 10; l++) c.v[l] = tab[mag][l][lane];
+            Q = qd_add_cached(Q, c, negative, role);
+        }
+    }
+    // R = s * H (32 windows of 8 bits, fixed-base table) - Q
+    qd_point R = qd_identity(role);
 #pragma unroll 1
     for (u32 w = 0; w < 32; w++) {
         u32 b = (sw[w >> 2] >> ((w & 3) * 8)) & 255;
-        if (b) R = ge_madd(R, ge_niels_load(htab + 32ull * (w * 256 + b)));
+        R = qd_madd(R, htab + 32ull * (w * 256 + b), false, role);
     }
-    // e * P with 4-bit windows
-    ge P = ge_from_niels_affine(ge_niels_load(pts + 32ull * sg.key_pt));
-    ge tbl[16];
-    tbl[0] = ge_identity(); tbl[1] = P;
-#pragma unroll 1
-    for (int k = 2; k < 16; k++) tbl[k] = ge_add(tbl[k - 1], P);
-    ge Q = ge_identity();
-#pragma unroll 1
-    for (int k = 63; k >= 0; k--) {
-        Q = ge_double(ge_double(ge_double(ge_double(Q))));
-        u32 nib = (ew[k >> 3] >> ((k & 7) * 4)) & 15;
-        Q = ge_add(Q, tbl[nib]);
+    R = qd_add_cached(R, qd_to_cached(Q, role), true, role);
+    if (q < n) qd_store(r_out + 32ull * q, R, role);
+}
+
+__global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u64 *__restrict__ state,
+                                                  const u32 *__restrict__ r_in, const u8 *__restrict__ ok, const u8 *__restrict__ ms_hash, u32 *__restrict__ tx_err) {
+    wave_priority_high();
+    __shared__ u8 tail[2 * SIG_RATE_WORDS][64][8];       // [word][lane][byte]: the last one or two blocks of each signature
+    const u32 lane = threadIdx.x;
+    u32 i = blockIdx.x * blockDim.x + lane;
+    if (i >= n) return;
+    const dev_sig sg = sigs[i];
+    if (!ok[sg.key_pt]) { if (sg.key_err_key) raise_err(tx_err, sg.tx, sg.key_err_key); return; }
+    u32 rw[8]; ristretto_encode_words(rw, ge_load(r_in + 32ull * i));
+    // tail = rest of pk || msg, enc(R), 0x06, zeros, 0x80 at the end of the last block
+    const sig_stream st = sig_stream_of(sg, bytes, ms_hash);
+    const u32 total = 32 + sg.msg_len, done = 72 * sig_whole_blocks(sg), rest = total - done;     // rest < 72, or 64 for a co-signature
+    const u32 blocks = (rest + 32) / 72 + 1;
+#pragma unroll
+    for (int w = 0; w < 2 * (int)SIG_RATE_WORDS; w++) *(u64 *)tail[w][lane] = 0;
+    for (u32 j = 0; j < rest; j++) tail[j >> 3][lane][j & 7] = st.at(done + j);
+    for (u32 j = 0; j < 32; j++) { u32 o = rest + j; tail[o >> 3][lane][o & 7] = (u8)(rw[j >> 2] >> ((j & 3) * 8)); }
+    { u32 o = rest + 32; tail[o >> 3][lane][o & 7] ^= 0x06; o = 72 * blocks - 1; tail[o >> 3][lane][o & 7] ^= 0x80; }
+    u64 a[25];
+#pragma unroll
+    for (int w = 0; w < 25; w++) a[w] = state[(u64)w * n + i];
+#pragma unroll
+    for (int w = 0; w < (int)SIG_RATE_WORDS; w++) a[w] ^= *(const u64 *)tail[w][lane];
+    keccak_f1600_regs(a);
+    if (blocks == 2) {
+#pragma unroll
+        for (int w = 0; w < (int)SIG_RATE_WORDS; w++) a[w] ^= *(const u64 *)tail[SIG_RATE_WORDS + w][lane];
+        keccak_f1600_regs(a);
     }
-    R = ge_sub(R, Q);
-    u32 rw[8]; ristretto_encode_words(rw, R);
-    u8 rb[32];
-    for (int k = 0; k < 8; k++) { rb[4 * k] = (u8)rw[k]; rb[4 * k + 1] = (u8)(rw[k] >> 8); rb[4 * k + 2] = (u8)(rw[k] >> 16); rb[4 * k + 3] = (u8)(rw[k] >> 24); }
-    sponge sp; sp.init(72, 0x06);
-    sp.absorb(bytes + sg.key_off, 32);
-    if (sg.hash_idx != 0xffffffffu) sp.absorb(ms_hash + 32ull * sg.hash_idx, 32);
-    else sp.absorb(bytes + sg.msg_off, sg.msg_len);
-    sp.absorb(rb, 32);
-    u8 h[64]; sp.squeeze(h, 64);
-    u32 cw[8]; sc_to_words(cw, sc_from_wide_bytes(h));
+    u32 hw[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { hw[2 * k] = (u32)a[k]; hw[2 * k + 1] = (u32)(a[k] >> 32); }
+    u32 cw[8]; sc_to_words(cw, sc_from_wide_words(hw));
     u32 diff = 0;
-    for (int k = 0; k < 8; k++) diff |= cw[k] ^ ew[k];
+    for (int k = 0; k < 8; k++) {
+        const u8 *e = bytes + sg.sig_off + 32 + 4 * k;
+        diff |= cw[k] ^ ((u32)e[0] | ((u32)e[1] << 8) | ((u32)e[2] << 16) | ((u32)e[3] << 24));
+    }
     if (diff) raise_err(tx_err, sg.tx, sg.err_key);
 }
 
-
-void launch_schnorr(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u8 *ok, const u32 *htab, const u8 *ms_hash, u32 *tx_err) {
-    if (n) hipLaunchKernelGGL(k_schnorr, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, pts, ok, htab, ms_hash, tx_err);
+void launch_sig_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, u64 *state) {
+    if (n) hipLaunchKernelGGL(k_sig_absorb, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state);
+}
+void launch_sig_point(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u32 *htab, u32 *r_out) {
+    if (n) hipLaunchKernelGGL(k_sig_point, dim3(grid_for(n, SIG_QUADS)), dim3(64), 0, st, bytes, sigs, n, pts, htab, r_out);
+}
+void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err) {
+    if (n) hipLaunchKernelGGL(k_sig_final, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state, r_in, ok, ms_hash, tx_err);
 }
 
 }  // namespace xhe

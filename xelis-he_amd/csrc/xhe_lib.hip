@@ -90,7 +90,7 @@ struct xhe_ctx {
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] first decode pass + ledger scan, [1] signatures, [2] static-generator scalars,
                                                                   // [3] second decode pass; all at the default priority
-    hipEvent_t ev_transcript = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_sig_absorbed = nullptr, ev_transcript = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -111,13 +111,13 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream;
+    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed})
             b->release();
@@ -221,7 +221,7 @@ xhe_ctx *xhe_create(int device_id) {
     ctx->device = device_id;
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
               hipStreamCreate(&ctx->side[2]) == hipSuccess && hipStreamCreate(&ctx->side[3]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_transcript, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
+    for (hipEvent_t *e : {&ctx->ev_sig_absorbed, &ctx->ev_transcript, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -235,7 +235,7 @@ void xhe_destroy(xhe_ctx *ctx) {
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_transcript, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_sig_absorbed, ctx->ev_transcript, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
@@ -358,7 +358,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     RS(gh, 72ull * n_parts); RS(gh_sums, 72ull * 256); RS(rp_ctx, 36ull * RPC_SCALARS * hb.n_txs); RS(rp_acc, 72ull * hb.nm_cap);
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
-    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words);
+    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.sigs.size()); RS(sig_r, 128ull * hb.sigs.size());
     // partial column sums of the range-proof scalar matrix: one row per tile of transactions
     {
         u64 worst = 0;
@@ -468,14 +468,22 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
                       B->tr_stream.as<u64>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
     HIPCHK(ctx, hipEventRecord(ctx->ev_transcript, st));
-    // side stream 1: public keys, then the signatures
+    // side stream 2: the signatures' hashing up to the last block (needs no point)
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->side[2], ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("signature_hash", ctx->side[2]));
+    launch_sig_absorb(ctx->side[2], bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>());
+    HIPCHK(ctx, tm.close(ctx->side[2]));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_sig_absorbed, ctx->side[2]));
+    // side stream 1: public keys, then the signatures' points and the end of their hashing
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
     if (exp_flags() & 1) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_transcript, 0));
     HIPCHK(ctx, tm.open("signatures", s1));
     launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
     HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s1));
     launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
-    launch_schnorr(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ok, ctx->htab.as<u32>(), B->ms_hash.as<u8>(), tx_err);
+    launch_sig_point(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>());
+    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_sig_absorbed, 0));
+    launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.close(s1));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
     // side stream 0: ledger and transfer ciphertexts, then the ledger as a prefix sum
