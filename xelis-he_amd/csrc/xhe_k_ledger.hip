@@ -43,6 +43,7 @@ __device__ __forceinline__ ct_acc block_scan_ct(ct_acc v, u32 *lds /* SCAN_BLOCK
 // phase 1: per-thread sums, block scan; writes each thread's exclusive prefix inside its block and the block total
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_local(const dev_op *__restrict__ ops, u32 n_ops, const u32 *__restrict__ pts, const u32 *__restrict__ gtab,
                                                            u32 *__restrict__ thread_excl, u32 *__restrict__ block_tot) {
+    wave_priority_high();
     __shared__ u32 lds[SCAN_BLOCK * 64];
     u32 t = threadIdx.x, gt = blockIdx.x * SCAN_BLOCK + t;
     ct_acc acc = ct_identity();
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_local(const dev_op *__restr
 }
 // phase 2: one block turns the block totals into exclusive block prefixes (in place)
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(u32 *__restrict__ block_tot, u32 n_blocks) {
+    wave_priority_high();
     __shared__ u32 lds[SCAN_BLOCK * 64];
     u32 t = threadIdx.x;
     u32 per = (n_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -81,6 +83,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const dev_op *__restr
                                                            const u32 *__restrict__ thread_excl, const u32 *__restrict__ block_excl,
                                                            const u32 *__restrict__ slot_last_op, u32 *__restrict__ slot_base, u32 *__restrict__ slot_final,
                                                            u32 *__restrict__ emit_incl) {
+    wave_priority_high();
     u32 gt = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     if (gt * SCAN_K >= n_ops) return;
     ct_acc acc = ct_add(ct_load(block_excl + 64ull * blockIdx.x), ct_load(thread_excl + 64ull * gt));
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const dev_op *__restr
 // phase 4a: sender ciphertexts read by the equality proofs, as affine-Niels points
 __global__ void __launch_bounds__(256, 2) k_scan_emit(const u32 *__restrict__ emit_incl, const u32 *__restrict__ emit_slot, const u32 *__restrict__ slot_base,
                                                       u32 n_emit, u32 emit_pt_base, u32 *__restrict__ pts, u8 *__restrict__ ok) {
+    wave_priority_high();
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per point (2 per emitted ciphertext)
     if (g >= 2 * n_emit) return;
     u32 e = g >> 1, which = g & 1;

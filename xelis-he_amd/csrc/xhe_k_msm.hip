@@ -104,6 +104,7 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32
 
 // digits[w * n + i]: bit 15 = sign, bits 0..14 = magnitude (0 = no contribution)
 __global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits) {
+    wave_priority_high();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 s[8];
@@ -116,6 +117,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scal
 }
 // workgroup (tile, window): counts of the tile's digits per bucket -> tile_hist[(w * tiles + tile) * B + b]
 __global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, u32 *__restrict__ tile_hist) {
+    wave_priority_high();
     extern __shared__ u32 cnt[];
     const u32 tile = blockIdx.x, w = blockIdx.y;
     for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = 0;
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__r
 }
 // thread per (window, bucket): tile_hist becomes the count of the earlier tiles, hist the bucket's total
 __global__ void __launch_bounds__(256) k_msm_tile_prefix(u32 *__restrict__ tile_hist, msm_plan p, u32 tiles, u32 *__restrict__ hist) {
+    wave_priority_high();
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.W * p.B) return;
     u32 w = g / p.B, b = g % p.B;
@@ -156,6 +159,7 @@ __device__ __forceinline__ u32 block_sum_256(u32 v, u32 *lds /* 4 */) {
     return r;
 }
 __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32 *__restrict__ hist, u32 count, u32 *__restrict__ tile_sums) {
+    wave_priority_high();
     __shared__ u32 lds[4];
     u32 i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
     u32 v = 0;
@@ -165,6 +169,7 @@ __global__ void __launch_bounds__(256) k_msm_scan_tiles(const u32 *__restrict__ 
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = r;
 }
 __global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, u32 count, const u32 *__restrict__ tile_sums, u32 *__restrict__ offsets) {
+    wave_priority_high();
     __shared__ u32 lds[4];
     __shared__ u32 part[256];
     u32 t = threadIdx.x;
@@ -195,6 +200,7 @@ __global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, 
 // workgroup (tile, window): LDS counters start at the tile's first position inside each bucket's segment
 __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
                                                      const u32 *__restrict__ offsets, u32 *__restrict__ sorted, u64 sorted_cap) {
+    wave_priority_high();
     extern __shared__ u32 cnt[];
     const u32 tile = blockIdx.x, w = blockIdx.y;
     const u32 *pre = tile_hist + ((u64)w * tiles + tile) * p.B;
@@ -232,6 +238,7 @@ __device__ __forceinline__ ge ge_select(const ge &a, const ge &b, bool flag) {
 __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
                                                            const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets, u32 M,
                                                            u32 *__restrict__ bucket_sums, u32 *__restrict__ chunk_sums) {
+    wave_priority_high();
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 total = offsets[n_buckets];
     u64 start64 = (u64)t * M;
@@ -267,6 +274,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict
 // add their partial sums.  big_list[0] counts the buckets deferred to k_msm_merge_big, ids from big_list[1].
 __global__ void __launch_bounds__(256, 2) k_msm_merge(const u32 *__restrict__ offsets, u32 n_buckets, u32 M, const u32 *__restrict__ chunk_sums,
                                                       u32 *__restrict__ bucket_sums, u32 *__restrict__ big_list, u32 big_cap) {
+    wave_priority_high();
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_buckets) return;
     u32 lo = offsets[g], hi = offsets[g + 1];
@@ -287,6 +295,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_merge(const u32 *__restrict__ of
 // 256, waves fold with shuffles, LDS joins the four waves
 __global__ void __launch_bounds__(256, 2) k_msm_merge_big(const u32 *__restrict__ offsets, u32 M, const u32 *__restrict__ chunk_sums, u32 *__restrict__ bucket_sums,
                                                           const u32 *__restrict__ big_list, u32 big_cap) {
+    wave_priority_high();
     __shared__ u32 part[3][40];
     u32 count = big_list[0]; if (count > big_cap) count = big_cap;
     u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

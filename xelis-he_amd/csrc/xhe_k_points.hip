@@ -86,6 +86,7 @@ static constexpr u32 DECODE_MAX_BLOCKS = 512;
 // wait for); list == null: all n entries except those of the first pass
 __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok) {
+    if (list) wave_priority_high(); else wave_priority_mid();      // listed points head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         u32 i = g;
         if (list) i = list[g];

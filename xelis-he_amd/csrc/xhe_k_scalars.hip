@@ -10,6 +10,7 @@ namespace xhe {
 __global__ void __launch_bounds__(256, 2) k_sigma_cm(const u8 *__restrict__ bytes, const dev_cm *__restrict__ cms, const dev_tx *__restrict__ txs, u32 n,
                                                      const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
                                                      u32 *__restrict__ term_point, u32 *__restrict__ gh) {
+    wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const dev_cm c = cms[i];
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(256, 2) k_sigma_cm(const u8 *__restrict__ byte
 __global__ void __launch_bounds__(256, 2) k_sigma_xf(const u8 *__restrict__ bytes, const dev_xfer *__restrict__ xfers, const dev_tx *__restrict__ txs, u32 n,
                                                      const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
                                                      u32 *__restrict__ term_point, u32 *__restrict__ gh) {
+    wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const dev_xfer x = xfers[i];
@@ -88,10 +90,21 @@ __global__ void __launch_bounds__(256) k_sc_sum_partial(const u32 *__restrict__ 
 }
 
 // ---- range proofs ----------------------------------------------------------------------------------
+// The verification equation of one aggregated range proof (bulletproofs RangeProof::verify_multiple, called at
+// /root/reference/src/tx/verify.rs:504-513) holds iff it holds after multiplying every scalar of that proof by
+// one non-zero factor.  Its inverses (u_j^-2 on R_j, s_i = prod u_j^(+-1), y^-i) all disappear under the
+// factor kappa = (prod u_j)^2 * y^(nm-1), so the proof's random weight is taken as rho * kappa (as uniform as
+// rho, which is drawn independently of the proof) and no scalar is ever inverted:
+//   U = prod u_j,  U2[b] = u_(lg-1-b)^2,  Y2[b] = y^(2^b),  Yt = y^(nm-1) = prod Y2[b],  rho' = rho U^2 Yt
+//   A: rho'   S: rho' x   T_1: rho' c x   T_2: rho' c x^2   L_j: rho' u_j^2   R_j: rho Yt prod_(k != j) u_k^2
+//   V_k: rho' c z^2 z^k   B: rho' (w (t_x - a b) + c (delta - t_x))   B_blinding: -rho' (e_bl + c t_x_bl)
+//   G_i: -rho' z - rho a U Yt    prod_(b in i) U2[b]
+//   H_i:  rho' z - rho b U       prod_(b not in i) Y2[b] U2[b]
+//               + rho z^2 U^2    prod_(b in i) E[b]  prod_(b not in i) Y2[b],   E[b] = 2^(2^b) (b < 6), z^(2^(b-6)) (b >= 6)
 // per-transaction context for the matrix kernel, Montgomery limbs (9 words each)
-static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_H2 = 3, RPC_COEF_H3 = 4, RPC_U2 = 5 /* 16 */, RPC_Y2INV = 21 /* 16 */,
-                     RPC_E = 37 /* 6 */, RPC_F = 43 /* 10 */;
-static_assert(RPC_F + 10 == RPC_SCALARS, "context layout");
+static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_H2 = 3, RPC_COEF_H3 = 4, RPC_U2 = 5 /* 16 */, RPC_YU = 21 /* 16 */,
+                     RPC_Y2 = 37 /* 16 */, RPC_E = 53 /* 16 */;
+static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 
 __global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const dev_cm *__restrict__ cms,
                                                 const dev_xfer *__restrict__ xfers, u32 n_txs, const u32 *__restrict__ chal, const u32 *__restrict__ seed,
@@ -124,99 +137,163 @@ __global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, co
     sc rho = prf_scalar(seed, 3, i), c = prf_scalar(seed, 4, i);
     u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * i;
 
-    // one inversion for y and all u_j: prefix products then back-substitution
-    sc u[16], pre[17];
-    pre[0] = y;
-    for (u32 j = 0; j < lg; j++) { u[j] = load_scalar_words(ch + 32 + 8 * j); pre[j + 1] = sc_mul(pre[j], u[j]); }
-    sc inv = sc_invert(pre[lg]);
-    sc allinv = sc_one();
-    sc rho_c = sc_mul(rho, c);
-    for (int j = (int)lg - 1; j >= 0; j--) {
-        sc u_inv = sc_mul(inv, pre[j]);          // 1/u_j
-        inv = sc_mul(inv, u[j]);
-        allinv = sc_mul(allinv, u_inv);
-        sc u2 = sc_mul(u[j], u[j]), ui2 = sc_mul(u_inv, u_inv);
-        store_scalar_words(s + 8 * (4 + 2 * j), sc_mul(rho, u2));            // L_j
-        store_scalar_words(s + 8 * (4 + 2 * j + 1), sc_mul(rho, ui2));       // R_j
-        store_sc_limbs(ctx + 9 * (RPC_U2 + (lg - 1 - j)), u2);               // bit (lg-1-j) of the index selects u_j^2
-    }
-    sc y_inv = inv;                               // after removing every u_j
-    sc zz = sc_mul(z, z);
-    store_scalar_words(s, rho);                                  // A
-    store_scalar_words(s + 8, sc_mul(rho, x));                   // S
-    store_scalar_words(s + 16, sc_mul(rho_c, x));                // T_1
-    store_scalar_words(s + 24, sc_mul(sc_mul(rho_c, x), x));     // T_2
-    {
-        sc v = sc_mul(rho_c, zz);
-        for (u32 k = 0; k < A + T; k++) { store_scalar_words(s + 8 * (4 + 2 * lg + k), v); v = sc_mul(v, z); }
-    }
-    // delta(y, z) = (z - zz) * sum_{i<nm} y^i - z^3 * (2^64 - 1) * sum_{j<m} z^j, sums as products of (1 + q^(2^k))
-    sc sum_y = sc_one(), sum_z = sc_one();
+    // powers of y, the sum of the y^i as the product of (1 + y^(2^k)), Yt = y^(nm-1)
+    sc sum_y = sc_one(), yt = sc_one();
     {
         sc q = y;
-        for (u32 k = 0; k < lg; k++) { sum_y = sc_mul(sum_y, sc_add(sc_one(), q)); q = sc_mul(q, q); }
+        for (u32 k = 0; k < lg; k++) {
+            store_sc_limbs(ctx + 9 * (RPC_Y2 + k), q);
+            sum_y = sc_mul(sum_y, sc_add(sc_one(), q)); yt = sc_mul(yt, q);
+            q = sc_mul(q, q);
+        }
+    }
+    // squares of the u_j: prefix products left to right, then suffix products on the way back
+    sc u2[16], pre[17];
+    sc U = sc_one();
+    pre[0] = sc_one();
+    for (u32 j = 0; j < lg; j++) {
+        sc u = load_scalar_words(ch + 32 + 8 * j);
+        U = sc_mul(U, u);
+        u2[j] = sc_mul(u, u);
+        pre[j + 1] = sc_mul(pre[j], u2[j]);
+    }
+    const sc UU = pre[lg];                            // U^2
+    const sc rho_yt = sc_mul(rho, yt), rho_k = sc_mul(rho_yt, UU);       // rho' = rho * kappa
+    const sc rho_kc = sc_mul(rho_k, c);
+    {
+        sc suffix = rho_yt;                           // rho Yt prod_(k > j) u_k^2
+        for (int j = (int)lg - 1; j >= 0; j--) {
+            store_scalar_words(s + 8 * (4 + 2 * j), sc_mul(rho_k, u2[j]));               // L_j
+            store_scalar_words(s + 8 * (4 + 2 * j + 1), sc_mul(suffix, pre[j]));         // R_j
+            suffix = sc_mul(suffix, u2[j]);
+            const u32 bit = lg - 1 - (u32)j;          // bit (lg-1-j) of the index selects u_j
+            store_sc_limbs(ctx + 9 * (RPC_U2 + bit), u2[j]);
+            store_sc_limbs(ctx + 9 * (RPC_YU + bit), sc_mul(u2[j], load_sc_limbs(ctx + 9 * (RPC_Y2 + bit))));
+        }
+    }
+    sc zz = sc_mul(z, z);
+    store_scalar_words(s, rho_k);                                  // A
+    store_scalar_words(s + 8, sc_mul(rho_k, x));                   // S
+    store_scalar_words(s + 16, sc_mul(rho_kc, x));                 // T_1
+    store_scalar_words(s + 24, sc_mul(sc_mul(rho_kc, x), x));      // T_2
+    {
+        sc v = sc_mul(rho_kc, zz);
+        for (u32 k = 0; k < A + T; k++) { store_scalar_words(s + 8 * (4 + 2 * lg + k), v); v = sc_mul(v, z); }
+    }
+    // delta(y, z) = (z - zz) * sum_{i<nm} y^i - z^3 * (2^64 - 1) * sum_{j<m} z^j, the z sum as a product of (1 + z^(2^k)) as well;
+    // E[b]: 2^(2^b) for the bits inside a 64-bit value, z^(2^(b-6)) for the bits of the value's index
+    sc sum_z = sc_one();
+    {
+        sc q = sc_from_u64(2);
+        for (u32 k = 0; k < 6; k++) { store_sc_limbs(ctx + 9 * (RPC_E + k), q); q = sc_mul(q, q); }
         q = z;
-        for (u32 k = 0; k + 6 < lg; k++) { sum_z = sc_mul(sum_z, sc_add(sc_one(), q)); q = sc_mul(q, q); }
+        for (u32 k = 0; k + 6 < lg; k++) { store_sc_limbs(ctx + 9 * (RPC_E + 6 + k), q); sum_z = sc_mul(sum_z, sc_add(sc_one(), q)); q = sc_mul(q, q); }
     }
     sc sum_2 = sc_from_u64(0xffffffffffffffffULL);
     sc delta = sc_sub(sc_mul(sc_sub(z, zz), sum_y), sc_mul(sc_mul(sc_mul(zz, z), sum_2), sum_z));
     sc b_scalar = sc_add(sc_mul(w, sc_sub(t_x, sc_mul(a, b))), sc_mul(c, sc_sub(delta, t_x)));
     sc bb_scalar = sc_neg(sc_add(e_bl, sc_mul(c, t_x_bl)));
-    store_sc_limbs(gh + 18ull * i, sc_norm(sc_mul(rho, b_scalar)));
-    store_sc_limbs(gh + 18ull * i + 9, sc_norm(sc_mul(rho, bb_scalar)));
+    store_sc_limbs(gh + 18ull * i, sc_norm(sc_mul(rho_k, b_scalar)));
+    store_sc_limbs(gh + 18ull * i + 9, sc_norm(sc_mul(rho_k, bb_scalar)));
     // context
-    sc rho_z = sc_mul(rho, z);
+    sc rho_z = sc_mul(rho_k, z), rho_u = sc_mul(rho, U);
     store_sc_limbs(ctx + 9 * RPC_RHO_Z, rho_z);
     store_sc_limbs(ctx + 9 * RPC_NEG_RHO_Z, sc_neg(rho_z));
-    store_sc_limbs(ctx + 9 * RPC_COEF_G, sc_neg(sc_mul(sc_mul(rho, a), allinv)));
-    store_sc_limbs(ctx + 9 * RPC_COEF_H2, sc_mul(rho, zz));
-    store_sc_limbs(ctx + 9 * RPC_COEF_H3, sc_neg(sc_mul(sc_mul(rho, b), allinv)));
-    {
-        sc q = y_inv;                             // y^-(2^k)
-        for (u32 k = 0; k < lg; k++) { store_sc_limbs(ctx + 9 * (RPC_Y2INV + k), q); q = sc_mul(q, q); }
-        q = sc_add(y_inv, y_inv);                 // (2/y)^(2^k)
-        for (u32 k = 0; k < 6; k++) { store_sc_limbs(ctx + 9 * (RPC_E + k), q); q = sc_mul(q, q); }
-        // (z * y^-64)^(2^k): y^-64 = Y2INV[6]
-        sc y64 = y_inv;
-        for (u32 k = 0; k < 6; k++) y64 = sc_mul(y64, y64);
-        q = sc_mul(z, y64);
-        for (u32 k = 0; k + 6 < lg; k++) { store_sc_limbs(ctx + 9 * (RPC_F + k), q); q = sc_mul(q, q); }
-    }
+    store_sc_limbs(ctx + 9 * RPC_COEF_G, sc_neg(sc_mul(sc_mul(rho_u, yt), a)));
+    store_sc_limbs(ctx + 9 * RPC_COEF_H2, sc_mul(sc_mul(rho, UU), zz));
+    store_sc_limbs(ctx + 9 * RPC_COEF_H3, sc_neg(sc_mul(rho_u, b)));
 }
 
-// thread per (tile of rows_per_thread transactions of the lg-group, i): partial column sums of the scalars
-// of G_i and H_i, written as row `tile` of part[tiles][2 * 2^lg]
-__global__ void __launch_bounds__(256, 2) k_rp_matrix(const u32 *__restrict__ group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *__restrict__ rp_ctx,
-                                                      const u32 *__restrict__ rp_err, u32 *__restrict__ part) {
-    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 nm = 1u << lg;
-    u32 tile = (u32)(g >> lg), idx = (u32)g & (nm - 1);
-    u64 r0 = (u64)tile * rows_per_thread;
-    if (r0 >= n_rows) return;
-    u32 r1 = (u32)((r0 + rows_per_thread < n_rows) ? r0 + rows_per_thread : n_rows);
-    sc sum_g = sc_zero(), sum_h = sc_zero();
+// Workgroup per tile of rows_per_thread transactions of the lg-group: partial column sums of the scalars of
+// G_i and H_i, written as row `tile` of part[tiles][2 * 2^lg].  Per transaction and index i three products over
+// the bits of i are needed (s_i, its mirror times y^-i, z^j 2^k y^-i).  A product over the bits of i is the
+// product of one factor for the low bits and one for the high bits, so the workgroup first fills, per
+// transaction, two small tables per product in LDS (2^l + 2^h entries, l + h = lg) and every element then costs
+// three multiplications instead of 2.5 lg.  (Products: see the table above k_rp_prep.)
+static constexpr u32 RPM_THREADS = 256;
+// Groups with fewer than 256 generators per side run 256 >> lg transactions side by side ("slots"), each slot
+// writing its own row of part[]; larger groups give every thread several indices.
+__global__ void __launch_bounds__(RPM_THREADS) k_rp_matrix(const u32 *__restrict__ group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *__restrict__ rp_ctx,
+                                                            const u32 *__restrict__ rp_err, u32 *__restrict__ part) {
+    extern __shared__ u32 tab[];                       // [slot][product 0..2][2^l low entries | 2^h high entries][9]
+    const u32 nm = 1u << lg, l = (lg + 1) / 2, h = lg - l, n_lo = 1u << l, n_hi = 1u << h, per = n_lo + n_hi;
+    const u32 slots = rp_matrix_slots(lg);
+    const u32 tile = blockIdx.x, t = threadIdx.x;
+    const u64 r0 = (u64)tile * rows_per_thread;
+    const u32 r1 = (u32)((r0 + rows_per_thread < n_rows) ? r0 + rows_per_thread : n_rows);
+    const u32 my_slot = nm < RPM_THREADS ? t >> lg : 0, idx0 = nm < RPM_THREADS ? (t & (nm - 1)) : t;
+    const u32 mine = nm <= RPM_THREADS ? 1 : nm / RPM_THREADS;       // indices per thread: idx0 + k * 256
+    u32 *out = part + 9ull * (((u64)tile * slots + my_slot) * 2 * nm);
+    const bool in_regs = mine <= 4;
+    sc sum_g[4], sum_h[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) { sum_g[k] = sc_zero(); sum_h[k] = sc_zero(); }
+    if (!in_regs)                                     // many indices per thread: the sums live in part[] itself
+        for (u32 k = 0; k < mine; k++) { store_sc_limbs(out + 9ull * (idx0 + k * RPM_THREADS), sc_zero()); store_sc_limbs(out + 9ull * (nm + idx0 + k * RPM_THREADS), sc_zero()); }
     u32 pending = 0;
-    for (u32 r = (u32)r0; r < r1; r++) {
-        u32 tx = group_txs[r];
-        if (rp_err[tx]) continue;
-        const u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * tx;
-        sc sprod = load_sc_limbs(ctx + 9 * RPC_COEF_G), tprod = load_sc_limbs(ctx + 9 * RPC_COEF_H3), eprod = load_sc_limbs(ctx + 9 * RPC_COEF_H2);
-        for (u32 b = 0; b < lg; b++) {
-            sc u2 = load_sc_limbs(ctx + 9 * (RPC_U2 + b));
-            if ((idx >> b) & 1) {
-                sprod = sc_mul(sprod, u2);
-                tprod = sc_mul(tprod, load_sc_limbs(ctx + 9 * (RPC_Y2INV + b)));
-                eprod = sc_mul(eprod, load_sc_limbs(ctx + 9 * ((b < 6) ? (RPC_E + b) : (RPC_F + b - 6))));
+    for (u32 r = (u32)r0; r < r1; r += slots) {
+        __syncthreads();                               // the previous pass's tables are no longer read
+        for (u32 e = t; e < slots * 3 * per; e += RPM_THREADS) {
+            const u32 slot = e / (3 * per), e3 = e % (3 * per), p = e3 / per, q = e3 % per;
+            if (r + slot >= r1) continue;
+            const u32 tx = group_txs[r + slot];
+            if (rp_err[tx]) continue;
+            const u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * tx;
+            const bool high = q >= n_lo;
+            const u32 bits = high ? q - n_lo : q, base = high ? l : 0, nb = high ? h : l;
+            sc acc = high ? load_sc_limbs(ctx + 9 * (p == 0 ? RPC_COEF_G : p == 1 ? RPC_COEF_H3 : RPC_COEF_H2)) : sc_one();
+            for (u32 k = 0; k < nb; k++) {
+                const u32 b = base + k;
+                const bool set = (bits >> k) & 1;
+                if (p == 0) { if (set) acc = sc_mul(acc, load_sc_limbs(ctx + 9 * (RPC_U2 + b))); }
+                else if (p == 1) { if (!set) acc = sc_mul(acc, load_sc_limbs(ctx + 9 * (RPC_YU + b))); }
+                else acc = sc_mul(acc, load_sc_limbs(ctx + 9 * (set ? RPC_E + b : RPC_Y2 + b)));
+            }
+            store_sc_limbs(tab + 9 * e, acc);
+        }
+        __syncthreads();
+        const bool live = r + my_slot < r1 && !rp_err[group_txs[r + my_slot < r1 ? r + my_slot : r]];
+        if (live) {
+            const u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * group_txs[r + my_slot];
+            const u32 *tb = tab + 9 * (my_slot * 3 * per);
+            const sc neg_rho_z = load_sc_limbs(ctx + 9 * RPC_NEG_RHO_Z), rho_z = load_sc_limbs(ctx + 9 * RPC_RHO_Z);
+            auto element = [&](u32 idx, sc &g, sc &hh) {
+                const u32 lo = idx & (n_lo - 1), hi = idx >> l;
+                sc sprod = sc_mul(load_sc_limbs(tb + 9 * lo), load_sc_limbs(tb + 9 * (n_lo + hi)));
+                sc tprod = sc_mul(load_sc_limbs(tb + 9 * (per + lo)), load_sc_limbs(tb + 9 * (per + n_lo + hi)));
+                sc eprod = sc_mul(load_sc_limbs(tb + 9 * (2 * per + lo)), load_sc_limbs(tb + 9 * (2 * per + n_lo + hi)));
+                g = sc_add(neg_rho_z, sprod); hh = sc_norm(sc_add_lazy(sc_add(rho_z, eprod), tprod));
+            };
+            if (in_regs) {
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    if (k < mine) { sc g, hh; element(idx0 + k * RPM_THREADS, g, hh); sum_g[k] = sc_add(sum_g[k], g); sum_h[k] = sc_add(sum_h[k], hh); }
+                }
             } else {
-                tprod = sc_mul(tprod, u2);
+                for (u32 k = 0; k < mine; k++) {
+                    const u32 idx = idx0 + k * RPM_THREADS;
+                    sc g, hh; element(idx, g, hh);
+                    u32 *pg = out + 9ull * idx, *ph = out + 9ull * (nm + idx);
+                    store_sc_limbs(pg, sc_reduce_mont(sc_add(load_sc_limbs(pg), g)));
+                    store_sc_limbs(ph, sc_reduce_mont(sc_add(load_sc_limbs(ph), hh)));
+                }
             }
         }
-        sum_g = sc_add(sum_g, sc_add(load_sc_limbs(ctx + 9 * RPC_NEG_RHO_Z), sprod));
-        sum_h = sc_add(sum_h, sc_norm(sc_add_lazy(sc_add(load_sc_limbs(ctx + 9 * RPC_RHO_Z), eprod), tprod)));
-        if (++pending == 8) { sum_g = sc_reduce_mont(sum_g); sum_h = sc_reduce_mont(sum_h); pending = 0; }
+        if (in_regs && ++pending == 8) {
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) { sum_g[k] = sc_reduce_mont(sum_g[k]); sum_h[k] = sc_reduce_mont(sum_h[k]); }
+            pending = 0;
+        }
     }
-    store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + idx), sc_reduce_mont(sum_g));
-    store_sc_limbs(part + 9ull * ((u64)tile * 2 * nm + nm + idx), sc_reduce_mont(sum_h));
+    if (in_regs) {
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            if (k < mine) {
+                store_sc_limbs(out + 9ull * (idx0 + k * RPM_THREADS), sc_reduce_mont(sum_g[k]));
+                store_sc_limbs(out + 9ull * (nm + idx0 + k * RPM_THREADS), sc_reduce_mont(sum_h[k]));
+            }
+        }
+    }
 }
 // workgroup per column: acc[col] += sum over the rows of part[n_rows][2 * 2^lg]
 __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *__restrict__ acc /* 2*nm_cap scalars */) {
@@ -271,7 +348,9 @@ void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const de
 void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part) {
     if (!n_rows || !rows_per_thread) return;
     u64 tiles = ((u64)n_rows + rows_per_thread - 1) / rows_per_thread;
-    hipLaunchKernelGGL(k_rp_matrix, dim3(grid_for(tiles << lg, 256)), dim3(256), 0, st, group_txs, n_rows, rows_per_thread, lg, rp_ctx, rp_err, part);
+    u32 l = (lg + 1) / 2, h = lg - l;
+    u32 lds = rp_matrix_slots(lg) * 3u * ((1u << l) + (1u << h)) * 36u;
+    hipLaunchKernelGGL(k_rp_matrix, dim3((u32)tiles), dim3(RPM_THREADS), lds, st, group_txs, n_rows, rows_per_thread, lg, rp_ctx, rp_err, part);
 }
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc) {
     hipLaunchKernelGGL(k_rp_colsum, dim3(2u << lg), dim3(256), 0, st, mat, n_rows, lg, nm_cap, acc);

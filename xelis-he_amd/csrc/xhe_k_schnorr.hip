@@ -32,7 +32,6 @@ __device__ __forceinline__ u32 sig_whole_blocks(const dev_sig &sg) { return sg.h
 
 // state[w * n + i]: word w of signature i's sponge after its whole blocks
 __global__ void __launch_bounds__(64) k_sig_absorb(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, u64 *__restrict__ state) {
-    wave_priority_high();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const dev_sig sg = sigs[i];
@@ -85,7 +84,6 @@ static constexpr u32 SIG_QUADS = 16;          // signatures per 64-thread workgr
 
 __global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u32 *__restrict__ pts,
                                                   const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
-    wave_priority_high();
     __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
     const u32 lane = threadIdx.x, role = lane & 3;
     const u32 q = blockIdx.x * SIG_QUADS + (lane >> 2);
@@ -145,7 +143,6 @@ __global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, 
 
 __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u64 *__restrict__ state,
                                                   const u32 *__restrict__ r_in, const u8 *__restrict__ ok, const u8 *__restrict__ ms_hash, u32 *__restrict__ tx_err) {
-    wave_priority_high();
     __shared__ u8 tail[2 * SIG_RATE_WORDS][64][8];       // [word][lane][byte]: the last one or two blocks of each signature
     const u32 lane = threadIdx.x;
     u32 i = blockIdx.x * blockDim.x + lane;

@@ -134,6 +134,7 @@ __device__ __forceinline__ u64 transcript_gather(const u32 *__restrict__ desc, u
 __global__ void __launch_bounds__(64 * STAGE_ROWS) k_transcript_stage(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl,
                                                                       const u32 *__restrict__ segs, const u32 *__restrict__ list, const transcript_tile *__restrict__ tiles,
                                                                       u32 tile0, u64 *__restrict__ stream, u32 *__restrict__ tx_err, u32 *__restrict__ rp_err) {
+    wave_priority_high();
     const u32 tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, row = threadIdx.x >> 6;
     const transcript_tile tt = tiles[tile];
     const u32 i = list[64ull * tile + lane];

@@ -80,15 +80,18 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
 // the slots' resulting ciphertexts as 64-byte encodings (read back by the caller, not by any kernel)
 void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts);
 // proof scalars
-static constexpr u32 RPC_SCALARS = 53;    // Montgomery-limb scalars in a transaction's range-proof context
+static constexpr u32 RPC_SCALARS = 69;    // Montgomery-limb scalars in a transaction's range-proof context
 void launch_sigma_cm(hipStream_t st, const u8 *bytes, const dev_cm *cms, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point, u32 *gh);
 void launch_sigma_xf(hipStream_t st, const u8 *bytes, const dev_xfer *xfers, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point,
                      u32 *gh);
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out);
 void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *chal, const u32 *seed, u32 *scalars,
                     u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err);
-// rows_per_thread transactions per thread: part[ceil(n_rows / rows_per_thread)][2 * 2^lg] partial column sums, summed by launch_rp_colsum
-static inline u32 rp_rows_per_thread(u64 n_rows, u32 lg) { u64 r = (n_rows << lg) >> 17; return r < 1 ? 1u : r > 64 ? 64u : (u32)r; }
+// A workgroup takes rows_per_thread transactions of an lg-group, rp_matrix_slots(lg) of them side by side, and writes one row of
+// partial column sums per slot: part[ceil(n_rows / rows_per_thread) * slots][2 * 2^lg], summed by launch_rp_colsum
+XHE_HD u32 rp_matrix_slots(u32 lg) { return lg >= 8 ? 1u : 256u >> lg; }
+static inline u32 rp_rows_per_thread(u64 n_rows, u32 lg) { u64 r = n_rows / 512; u32 s = rp_matrix_slots(lg); return r < s ? s : r > 64 ? 64u : (u32)r; }
+static inline u64 rp_matrix_part_rows(u64 n_rows, u32 lg) { u32 rpt = rp_rows_per_thread(n_rows, lg); return ((n_rows + rpt - 1) / rpt) * rp_matrix_slots(lg); }
 void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part);
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc);
 void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point);

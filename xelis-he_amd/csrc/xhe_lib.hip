@@ -364,8 +364,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
         u64 worst = 0;
         for (u32 lg = 6; lg < 16; lg++) {
             u64 rows = hb.lg_groups[lg].size(); if (!rows) continue;
-            u32 rpt = rp_rows_per_thread(rows, lg);
-            worst = std::max<u64>(worst, ((rows + rpt - 1) / rpt) * (72ull << lg));
+            worst = std::max<u64>(worst, rp_matrix_part_rows(rows, lg) * (72ull << lg));
         }
         RS(rp_mat, worst);
     }
@@ -528,9 +527,8 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     for (u32 lg = 6; lg < 16; lg++) {
         u32 rows = (u32)hb.lg_groups[lg].size();
         if (!rows) continue;
-        u32 rpt = rp_rows_per_thread(rows, lg), tiles = (rows + rpt - 1) / rpt;
-        launch_rp_matrix(ss, B->group_txs.as<u32>() + B->group_off[lg], rows, rpt, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
-        launch_rp_colsum(ss, B->rp_mat.as<u32>(), tiles, lg, hb.nm_cap, B->rp_acc.as<u32>());
+        launch_rp_matrix(ss, B->group_txs.as<u32>() + B->group_off[lg], rows, rp_rows_per_thread(rows, lg), lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
+        launch_rp_colsum(ss, B->rp_mat.as<u32>(), (u32)rp_matrix_part_rows(rows, lg), lg, hb.nm_cap, B->rp_acc.as<u32>());
     }
     u32 sum_blocks = std::min<u32>(128, (n_parts + 255) / 256);
     launch_sc_sum_partial(ss, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
