@@ -324,7 +324,11 @@ __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh
     sc v;
     if (g < 2) {
         v = sc_zero();
-        for (u32 k = 0; k < n_parts; k++) v = sc_reduce_mont(sc_add(v, load_sc_limbs(gh_sums + 9ull * (2 * k + g))));
+        for (u32 k = 0; k < n_parts; k++) {
+            v = sc_add(v, load_sc_limbs(gh_sums + 9ull * (2 * k + g)));
+            if ((k & 7) == 7) v = sc_reduce_mont(v);
+        }
+        v = sc_reduce_mont(v);
     } else v = load_sc_limbs(acc + 9ull * (g - 2));
     store_scalar_words(scalars + 8ull * (static_term_off + g), v);
     term_point[static_term_off + g] = g;

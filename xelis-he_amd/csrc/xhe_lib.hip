@@ -3,7 +3,6 @@
 // (xhe_ingest.h); all field, group and hash arithmetic of the verification path runs in the kernels.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -21,7 +20,6 @@ using namespace xhe;
     } while (0)
 
 static std::string g_create_error;
-static unsigned exp_flags() { const char *e = getenv("XHE_EXP"); return e ? (unsigned)atoi(e) : 0u; }
 
 struct dev_buf {
     void *p = nullptr; size_t cap = 0;
@@ -63,7 +61,11 @@ struct stage_timer {
         spans.push_back(sp);
         return hipEventRecord(sp.a, s);
     }
-    hipError_t close(hipStream_t s) { return hipEventRecord(spans.back().b, s); }
+    // closes the span of that name (spans on different streams are open at the same time)
+    hipError_t close(const char *name, hipStream_t s) {
+        for (auto &sp : spans) if (!strcmp(sp.name, name)) return hipEventRecord(sp.b, s);
+        return hipErrorInvalidValue;
+    }
     // after every stream is synchronised
     void finish() {
         names.clear(); ms.clear();
@@ -88,9 +90,9 @@ struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits
 struct xhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] first decode pass + ledger scan, [1] signatures, [2] static-generator scalars,
-                                                                  // [3] second decode pass; all at the default priority
-    hipEvent_t ev_sig_absorbed = nullptr, ev_transcript = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};            // [0] ledger scan + static-generator scalars, [1] signatures, [2] bulk point decoding + signature
+                                                                  // hashing; with the main stream one per hardware queue, all at the default priority
+    hipEvent_t ev_sig_absorbed = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -220,8 +222,8 @@ xhe_ctx *xhe_create(int device_id) {
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
-              hipStreamCreate(&ctx->side[2]) == hipSuccess && hipStreamCreate(&ctx->side[3]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_sig_absorbed, &ctx->ev_transcript, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2], &ctx->ev_side_done[3]})
+              hipStreamCreate(&ctx->side[2]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_sig_absorbed, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -230,13 +232,13 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_sig_absorbed, ctx->ev_transcript, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2], ctx->ev_side_done[3]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->side[3]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->ev_sig_absorbed, ctx->ev_static_done, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -458,67 +460,61 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *tx_err = B->tx_err.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
     const u32 *sd = B->seed.as<u32>();
 
-    // Enqueue order = who gets wave slots first: the longest dependent chain (keys -> signatures), then the ledger
-    // scan's inputs, then the transcripts that head the main path, then the bulk of the point decoding.
-    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1], s3 = ctx->side[3];
+    // Four streams: the device exposes four hardware queues to a process, and streams that share a queue run one
+    // after the other.  Enqueue order = who gets wave slots first.
+    //   main     transcripts -> proof scalars -> multiscalar check -> verdict
+    //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
+    //   side 1   public keys -> signature points -> end of the signature hashes
+    //   side 2   every other point of the batch -> the signatures' hashing up to their last block
+    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1], s2 = ctx->side[2];
     HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
-    // main stream: transcripts (over the compressed bytes only)
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
                       B->tr_stream.as<u64>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_transcript, st));
-    // side stream 2: the signatures' hashing up to the last block (needs no point)
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->side[2], ctx->ev_setup, 0));
-    HIPCHK(ctx, tm.open("signature_hash", ctx->side[2]));
-    launch_sig_absorb(ctx->side[2], bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>());
-    HIPCHK(ctx, tm.close(ctx->side[2]));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_sig_absorbed, ctx->side[2]));
-    // side stream 1: public keys, then the signatures' points and the end of their hashing
+    // side 0: ledger and transfer ciphertexts, then the ledger as a prefix sum
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode_first", s0));
+    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close("decode_first", s0));
+    HIPCHK(ctx, tm.open("ledger_scan", s0));
+    launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
+                       B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
+    HIPCHK(ctx, tm.close("ledger_scan", s0));
+    // side 1: public keys, then the signatures' points
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
-    if (exp_flags() & 1) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_transcript, 0));
     HIPCHK(ctx, tm.open("signatures", s1));
     launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
     HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s1));
     launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
     launch_sig_point(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>());
-    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_sig_absorbed, 0));
-    launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
-    HIPCHK(ctx, tm.close(s1));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
-    // side stream 0: ledger and transfer ciphertexts, then the ledger as a prefix sum
-    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
-    if (exp_flags() & 4) HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_transcript, 0));
-    HIPCHK(ctx, tm.open("decode_first", s0));
-    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.close(s0));
-    HIPCHK(ctx, tm.open("ledger_scan", s0));
-    launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
-                       B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
-    HIPCHK(ctx, tm.close(s0));
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_decoded, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // keys, ledger inputs and the senders' new ciphertexts are in place
-    // side stream 3: every other point of the batch
-    HIPCHK(ctx, hipStreamWaitEvent(s3, ctx->ev_setup, 0));
-    if (exp_flags() & 2) HIPCHK(ctx, hipStreamWaitEvent(s3, ctx->ev_transcript, 0));
-    HIPCHK(ctx, tm.open("decode_rest", s3));
-    launch_decode_list(s3, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.close(s3));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[3], s3));
-    // side stream 0 again: resulting ledger ciphertexts, point-validity errors (need every point)
-    if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
-    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_side_done[3], 0));
-    launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
+    // side 2: every other point of the batch, then the signatures' hashing up to the last block (needs no point)
+    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode_rest", s2));
+    launch_decode_list(s2, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close("decode_rest", s2));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s2));
+    HIPCHK(ctx, tm.open("signature_hash", s2));
+    launch_sig_absorb(s2, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>());
+    HIPCHK(ctx, tm.close("signature_hash", s2));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_sig_absorbed, s2));
+    // side 1 again: the end of the signature hashes
+    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_sig_absorbed, 0));
+    launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
+    HIPCHK(ctx, tm.close("signatures", s1));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
+    // main: proof scalars
     HIPCHK(ctx, tm.mark("sigma_scalars", st));
     launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
     launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
     HIPCHK(ctx, tm.mark("rangeproof_scalars", st));
     launch_rp_prep(st, bytes, txs, cms, xfers, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh + 18ull * (n_cm + n_xf), rp_err);
     // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
-    // parts).  With fixed-base tables their whole contribution is evaluated on side stream 2 while the main
-    // stream sorts and accumulates the dynamic terms; without, they join the multiscalar check as terms.
+    // parts).  With fixed-base tables their whole contribution is evaluated on side 0 while the main stream
+    // sorts and accumulates the dynamic terms; without, they join the multiscalar check as terms.
     const bool use_tables = ctx->gen_tab_cap != 0 && hb.nm_cap <= ctx->gen_tab_cap;
-    hipStream_t ss = use_tables ? ctx->side[2] : st;
+    hipStream_t ss = use_tables ? s0 : st;
     if (use_tables) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_scalars, st));
         HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_scalars, 0));
@@ -536,14 +532,19 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     if (use_tables) {
         launch_static_eval(ss, ctx->gen_tab.as<u32>(), scalars + 8ull * hb.static_term_off, hb.nm_cap, ctx->gen_tab_cap, ctx->static_partials.as<u32>(),
                            ctx->static_sum.as<u32>());
-        HIPCHK(ctx, tm.close(ss));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], ss));
+        HIPCHK(ctx, tm.close("static_scalars", ss));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_static_done, ss));
     }
+    // side 0 again: resulting ledger ciphertexts, point-validity errors (need every point)
+    if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_side_done[2], 0));
+    launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
     HIPCHK(ctx, hipGetLastError());
     // merged multiscalar check: sigma terms + range-proof terms (+ static generators, unless their sum comes from the tables)
     msm_deps deps;
-    deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[3];
-    if (use_tables) { deps.extra_point = ctx->static_sum.as<u32>(); deps.extra_ready = ctx->ev_side_done[2]; }
+    deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[2];
+    if (use_tables) { deps.extra_point = ctx->static_sum.as<u32>(); deps.extra_ready = ctx->ev_static_done; }
     int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps);
     if (rc) return rc;
     HIPCHK(ctx, tm.mark("join_signatures", st));
