@@ -140,6 +140,10 @@ void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
  * events on the stream each stage runs on (stages on different streams overlap; "total" spans the main
  * stream).  names/ms arrays of length cap; returns the number of stages. */
 int32_t xhe_last_stage_times(const xhe_ctx *ctx, const char **names, float *ms, int32_t cap);
+/* How much the context measures: 2 (default) every stage, 1 only "before_accumulate", "msm_accumulate" (the bucket
+ * accumulation kernel), "after_accumulate" and "total", 0 nothing.  Every measured stage boundary is an event on
+ * its stream; level 0 or 1 keeps them out of the launch sequence.  No counterpart in the reference (diagnostics). */
+int32_t xhe_set_stage_timing(xhe_ctx *ctx, int32_t level);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,8 @@ def load_library():
     lib.xhe_ristretto_compress_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, u8p]
     lib.xhe_last_stage_times.restype = ctypes.c_int32
     lib.xhe_last_stage_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
+    lib.xhe_set_stage_timing.restype = ctypes.c_int32
+    lib.xhe_set_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     _lib = lib
     return lib
 
@@ -87,6 +89,10 @@ class Engine:
         out = (ctypes.c_uint8 * (32 * max(n, 1)))()
         self._check(self.lib.xhe_ristretto_compress_batch(self.ctx, n, xyzt128, out))
         return bytes(out)[:32 * n]
+
+    def set_stage_timing(self, level):
+        """2: every stage, 1: the bucket accumulation and the total only, 0: nothing."""
+        self._check(self.lib.xhe_set_stage_timing(self.ctx, int(level)))
 
     def stage_times(self):
         names = (ctypes.c_char_p * 64)()

@@ -77,7 +77,8 @@ __device__ __forceinline__ ge_niels ge_to_niels_normalize(const ge &p) {
 // the bucket reduction) raise their wave priority so the SIMD arbiter issues them ahead of the wide
 // throughput kernels (point decoding) that run beside them on other streams.
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
-// the point decoding: the multiscalar check waits for it, the signatures (default priority) have slack until the verdict
+// the point decoding and the static-generator scalars: the multiscalar check waits for them, the signatures (default
+// priority) have slack until the verdict
 __device__ __forceinline__ void wave_priority_mid() { __builtin_amdgcn_s_setprio(1); }
 
 // 64-bit rotate left by a constant as two v_alignbit_b32 (the generic shift/or form costs two 64-bit shifts and two ORs)

@@ -41,8 +41,14 @@ msm_plan msm_make_plan(u64 n) {
     u32 L = p.B / 4096; if (L < 1) L = 1;          // S = B/(64L) <= 64
     if (p.B < 64) L = 1;
     p.L = L; p.S = (p.B + 64 * L - 1) / (64 * L);
-    u64 entries = n * p.W;
-    p.M = entries < (1u << 16) ? 8 : entries < (1u << 20) ? 16 : 32;
+    // entries per accumulate chunk: about half a bucket's expected load (few buckets are cut into more than a handful of
+    // chunks, so the merge stays cheap), within 8..128 and small enough that the chunks still cover the 1024 SIMDs several times
+    u64 entries = n * p.W, per_bucket = n / p.B;
+    u32 M = 8;
+    while (M < 128 && 2ull * M <= per_bucket && entries / (2ull * M) >= 8192) M *= 2;
+    if (M < 16 && entries >= (1u << 16)) M = 16;
+    if (M < 32 && entries >= (1u << 20)) M = 32;
+    p.M = M;
     return p;
 }
 
@@ -103,9 +109,10 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32
 }
 
 // digits[w * n + i]: bit 15 = sign, bits 0..14 = magnitude (0 = no contribution)
-__global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits) {
+__global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits, u32 *__restrict__ big_count) {
     wave_priority_high();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) big_count[0] = 0;                       // the merge stage's list of oversized buckets starts empty
     if (i >= n) return;
     u32 s[8];
 #pragma unroll
@@ -446,6 +453,7 @@ __device__ __forceinline__ ge block_point_sum(ge acc, u32 (*part)[40]) {
 // scalars: B, H, G_vec[nm_cap], H_vec[nm_cap]; the tables hold B, H, G_vec[table_cap], H_vec[table_cap]
 __global__ void __launch_bounds__(256, 2) k_static_eval(const u32 *__restrict__ gen_tab, const u32 *__restrict__ scalars, u32 nm_cap, u32 table_cap,
                                                         u32 *__restrict__ partials) {
+    wave_priority_mid();
     __shared__ u32 part[3][40];
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     ge acc = ge_identity();
@@ -459,6 +467,7 @@ __global__ void __launch_bounds__(256, 2) k_static_eval(const u32 *__restrict__ 
     if (threadIdx.x == 0) ge_store(partials + 32ull * blockIdx.x, acc);
 }
 __global__ void __launch_bounds__(64) k_static_sum(const u32 *__restrict__ partials, u32 n, u32 *__restrict__ out) {
+    wave_priority_mid();
     u32 lane = threadIdx.x;
     ge acc = ge_identity();
     for (u32 i = lane; i < n; i += 64) acc = ge_add(acc, ge_load(partials + 32ull * i));
@@ -485,8 +494,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     const u32 tiles = (u32)msm_sort_tiles(n), lds_bytes = p.B * 4;
     unsigned short *digits = (unsigned short *)ws.digits;
     MARK("msm_histogram");
-    if ((e = hipMemsetAsync(ws.big_list, 0, 4, st)) != hipSuccess) return e;
-    if (n) hipLaunchKernelGGL(k_msm_digits, dim3(grid_for(n, 256)), dim3(256), 0, st, d_scalars, n, p, digits);
+    hipLaunchKernelGGL(k_msm_digits, dim3(n ? grid_for(n, 256) : 1), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list);
     hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
     hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);
     MARK("msm_scan");

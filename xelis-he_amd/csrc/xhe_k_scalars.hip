@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256, 2) k_sigma_xf(const u8 *__restrict__ byte
 // out[b*classes + j] = sum over i in block b's share of in[(i*classes + j)]
 __device__ __forceinline__ sc sc_reduce_mont(const sc &a) { return sc_mul(a, sc_one()); }
 __global__ void __launch_bounds__(256) k_sc_sum_partial(const u32 *__restrict__ in, u32 n, u32 classes, u32 *__restrict__ out) {
+    wave_priority_mid();
     __shared__ u32 lds[256 * 9];
     u32 t = threadIdx.x;
     for (u32 j = 0; j < classes; j++) {
@@ -215,6 +216,7 @@ static constexpr u32 RPM_THREADS = 256;
 // writing its own row of part[]; larger groups give every thread several indices.
 __global__ void __launch_bounds__(RPM_THREADS) k_rp_matrix(const u32 *__restrict__ group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *__restrict__ rp_ctx,
                                                             const u32 *__restrict__ rp_err, u32 *__restrict__ part) {
+    wave_priority_mid();
     extern __shared__ u32 tab[];                       // [slot][product 0..2][2^l low entries | 2^h high entries][9]
     const u32 nm = 1u << lg, l = (lg + 1) / 2, h = lg - l, n_lo = 1u << l, n_hi = 1u << h, per = n_lo + n_hi;
     const u32 slots = rp_matrix_slots(lg);
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(RPM_THREADS) k_rp_matrix(const u32 *__restrict
 }
 // workgroup per column: acc[col] += sum over the rows of part[n_rows][2 * 2^lg]
 __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *__restrict__ acc /* 2*nm_cap scalars */) {
+    wave_priority_mid();
     __shared__ u32 lds[256 * 9];
     u32 col = blockIdx.x, t = threadIdx.x;
     u32 nm = 1u << lg;
@@ -319,6 +322,7 @@ __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ mat, 
 // static terms: scalars of B, H (sums of the per-proof parts) and of G_i, H_i (column sums)
 __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh_sums /* n_parts x 2 */, u32 n_parts, const u32 *__restrict__ acc, u32 nm_cap,
                                                       u32 static_term_off, u32 *__restrict__ scalars, u32 *__restrict__ term_point) {
+    wave_priority_mid();
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= 2 + 2 * nm_cap) return;
     sc v;
