@@ -257,18 +257,35 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict
     u32 b = lo, bend = offsets[b + 1];
     bool began_before = offsets[b] < start;
     ge acc = ge_identity();
+    // The record of entry k + 1 is requested before the addition of entry k starts: the three dependent loads
+    // (sorted entry -> point index -> 96-byte record, mostly Infinity Cache hits) then overlap ~2000 instructions of arithmetic.
+    // An index that does not name a point (never the case for a consistent sort) reads record 0 and is skipped.
+    auto fetch = [&](u32 k, u32 &e, bool &valid, u32 raw[24]) {
+        e = sorted[k];
+        u32 idx = e & 0x7fffffffu;
+        valid = idx < n;
+        if (term_point) { idx = term_point[valid ? idx : 0]; valid = valid && idx < n_points; }
+        const uint4 *src = (const uint4 *)(niels + 32ull * (valid ? idx : 0));
+#pragma unroll
+        for (int j = 0; j < 6; j++) { uint4 v = src[j]; raw[4 * j] = v.x; raw[4 * j + 1] = v.y; raw[4 * j + 2] = v.z; raw[4 * j + 3] = v.w; }
+    };
+    u32 e_cur, raw_cur[24]; bool valid_cur;
+    fetch(start, e_cur, valid_cur, raw_cur);
     for (u32 k = start; k < stop; k++) {
+        u32 e_next = 0, raw_next[24]; bool valid_next = false;
+        if (k + 1 < stop) fetch(k + 1, e_next, valid_next, raw_next);
         if (k >= bend) {                              // bucket b ended exactly at k
             ge_store(began_before ? chunk_sums + 64ull * t : bucket_sums + 32ull * b, acc);
             acc = ge_identity(); began_before = false;
             do { b++; bend = offsets[b + 1]; } while (k >= bend);     // b < n_buckets since k < total
         }
-        u32 e = sorted[k];
-        u32 idx = e & 0x7fffffffu;
-        if (idx >= n) continue;                       // never taken for a consistent index; guards the gather
-        if (term_point) { idx = term_point[idx]; if (idx >= n_points) continue; }
-        ge_niels q = ge_niels_load(niels + 32ull * idx);
-        acc = ge_madd_signed(acc, q, (e >> 31) != 0);
+        if (valid_cur) {
+            ge_niels q; q.ypx = fe_unpack(raw_cur); q.ymx = fe_unpack(raw_cur + 8); q.xy2d = fe_unpack(raw_cur + 16);
+            acc = ge_madd_signed(acc, q, (e_cur >> 31) != 0);
+        }
+        e_cur = e_next; valid_cur = valid_next;
+#pragma unroll
+        for (int j = 0; j < 24; j++) raw_cur[j] = raw_next[j];
     }
     u32 *dst;
     if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
