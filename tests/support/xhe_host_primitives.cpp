@@ -117,3 +117,17 @@ long long xt_transcript_template_challenges(const u8 *rec, u64 len, u8 *out32, u
     return n;
 }
 }
+
+// Host ingest of a batch (xhe_ingest.h) on the CPU: returns the seconds one ingest_batch call took and a few
+// sizes of the tables it laid out, so that the layout can be checked and timed without a GPU.
+#include <chrono>
+#include "../../xelis-he_amd/csrc/xhe_ingest.h"
+extern "C" double xt_ingest(const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view *view, u64 out_counts[8]) {
+    auto t0 = std::chrono::steady_clock::now();
+    host_batch hb;
+    bool ok = ingest_batch(hb, records, offsets, n, *view);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out_counts[0] = ok; out_counts[1] = hb.n_points; out_counts[2] = hb.n_terms; out_counts[3] = hb.sigs.size();
+    out_counts[4] = hb.ops.size(); out_counts[5] = hb.tr_tiles.size(); out_counts[6] = hb.n_chal; out_counts[7] = hb.tr_plan.stream_words;
+    return sec;
+}

@@ -7,7 +7,7 @@ import pytest
 
 from helpers import oracle_verify_batch
 from xelis_he_amd import codes
-from xelis_he_amd.api import (NATIVE, Account, Ledger, SyntheticBatch, Transaction, TransactionBuilder, TransferBuilder,
+from xelis_he_amd.api import (NATIVE, Account, Ledger, SyntheticBatch, Transaction, TransactionBuilder, TransactionUnsigned, TransferBuilder,
                               VerificationError, LedgerOut, Verdict)
 
 pytestmark = pytest.mark.gpu
@@ -231,6 +231,51 @@ def test_seventeen_transfers_then_small(engine, oracle):
     bob, carol = Account([(NATIVE, 100)], "big-b"), Account([(NATIVE, 0)], "big-c")
     small = TransactionBuilder(1, bob.pubkey, ("transfers", [TransferBuilder(carol.pubkey, 10)]), 1, 0).build({NATIVE: 100}, bob.keypair, "small", bob)
     check_same(engine, oracle, [small], Ledger([bob, carol]), expect_accept=True)
+
+
+def _resigned(unsigned, keypair, edits, seed):
+    """A lying prover: the unsigned record with some bytes replaced, signed afterwards (so the signature is valid)."""
+    r = bytearray(unsigned.record)
+    for off, data in edits:
+        r[off:off + len(data)] = data
+    return TransactionUnsigned(bytes(r)).sign(keypair, seed)
+
+
+@pytest.mark.parametrize("n_transfers", [1, 8, 17])
+def test_range_proof_rejections(engine, oracle, n_transfers):
+    """Valid signature and sigma proofs, wrong range proof: the error is RangeProof (verify.rs:504-514), whatever part
+    of the proof is wrong.  The range proof is the last thing the transcript absorbs, so the sigma challenges are intact."""
+    alice = Account([(NATIVE, 5000)], "rp-a")
+    dests = [Account([(NATIVE, 0)], "rp-d%d" % i) for i in range(3)]
+    ts = [TransferBuilder(dests[i % 3].pubkey, 1 + i) for i in range(n_transfers)]
+    ledger = Ledger([alice] + dests)
+    u = TransactionBuilder(1, alice.pubkey, ("transfers", ts), 2, 0).build_unsigned({NATIVE: 5000}, alice.keypair, "rp%d" % n_transfers, alice)
+    check_same(engine, oracle, [u.sign(alice.keypair, "ok")], ledger, expect_accept=True)
+    m = 1
+    while m < n_transfers + 1:
+        m *= 2
+    lg = 6 + m.bit_length() - 1
+    rp = 16 + 4 * n_transfers + 49 + 320 * n_transfers
+    rec = u.record
+    flip = lambda off: (off, bytes([rec[off] ^ 1]))
+    cases = {
+        "t_x": [flip(rp + 128)], "t_x_blinding": [flip(rp + 160)], "e_blinding": [flip(rp + 192)],
+        "a": [flip(rp + 224 + 64 * lg)], "b": [flip(rp + 224 + 64 * lg + 32)],
+        "S := A": [(rp + 32, rec[rp:rp + 32])], "T_1 <-> T_2": [(rp + 64, rec[rp + 96:rp + 128]), (rp + 96, rec[rp + 64:rp + 96])],
+        "L_0 <-> R_0": [(rp + 224, rec[rp + 256:rp + 288]), (rp + 256, rec[rp + 224:rp + 256])],
+        "last R := last L": [(rp + 224 + 64 * (lg - 1) + 32, rec[rp + 224 + 64 * (lg - 1):rp + 224 + 64 * (lg - 1) + 32])],
+    }
+    for name, edits in cases.items():
+        bad = _resigned(u, alice.keypair, edits, "bad-" + name)
+        _, got = check_same(engine, oracle, [bad], ledger, expect_accept=False, expect_code=codes.ERR_RANGE_PROOF)
+        assert got[2] == -1, name
+    # a wrong proof among right ones is found too
+    good = u.sign(alice.keypair, "ok2")
+    bob = Account([(NATIVE, 100)], "rp-b")
+    other = TransactionBuilder(1, bob.pubkey, ("burn", NATIVE, 10), 1, 0).build({NATIVE: 100}, bob.keypair, "rp-burn", bob)
+    check_same(engine, oracle, [other, _resigned(u, alice.keypair, cases["a"], "bad-mixed")], Ledger([alice, bob] + dests), expect_accept=False,
+               expect_code=codes.ERR_RANGE_PROOF)
+    check_same(engine, oracle, [other, good], Ledger([alice, bob] + dests), expect_accept=True)
 
 
 def test_synthetic_batch(engine, oracle):

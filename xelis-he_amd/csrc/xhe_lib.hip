@@ -3,6 +3,8 @@
 // (xhe_ingest.h); all field, group and hash arithmetic of the verification path runs in the kernels.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -342,14 +344,24 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     HIPCHK(ctx, hipSetDevice(ctx->device));
     xhe_batch *B = new xhe_batch();
     host_batch &hb = B->hb;
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!getenv("XHE_UPLOAD_TIMES")) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[xhe upload] %s %.3f ms\n", what, std::chrono::duration<double>(now - t_start).count() * 1e3);
+        t_start = now;
+    };
     bool parsed = ingest_batch(hb, records, offsets, n_txs, *in);
+    lap("ingest");
     if (structural) *structural = hb.structural;
     *batch_out = B;
     B->n_balances = in->n_balances; B->n_accounts = in->n_accounts;
     B->in_cts.assign(in->balance_cts, in->balance_cts + 64 * in->n_balances);
     B->in_nonces.assign(in->account_nonces, in->account_nonces + in->n_accounts);
+    lap("ledger copies");
     if (!parsed) return 0;
     int32_t rc = ensure_tables(ctx, hb.nm_cap);
+    lap("tables");
     if (rc) { xhe_batch_free(ctx, B); *batch_out = nullptr; return rc; }
     hipStream_t st = ctx->stream;
     std::vector<u32> emit_slot(hb.cms.size(), 0);
@@ -362,6 +374,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
     UP(tx_err0, hb.tx_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
+    lap("uploads enqueued");
     u64 n_slots = hb.slot_of_used.size();
     u64 n_ops = hb.ops.size();
     u64 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -383,11 +396,13 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
         RS(rp_mat, worst);
     }
 #undef RS
+    lap("workspace allocations");
     // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
     HIPCHK(ctx, hipMemcpyAsync(B->pts.p, ctx->static_pts.p, 256 + 128ull * hb.nm_cap, hipMemcpyDeviceToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256 + 128ull * hb.nm_cap, ctx->static_pts.as<u8>() + 256 + 128ull * ctx->static_cap, 128ull * hb.nm_cap,
                                hipMemcpyDeviceToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    lap("synchronize");
     return 0;
 }
 
