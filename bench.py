@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--senders", type=int, default=1024, help="sender accounts per batch (1 = the reference bench's single chain)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="transactions of the batch the CPU baseline verifies (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo reduces through host memory, for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (only with --backend gloo)")
     return ap.parse_args()
 
 
@@ -66,12 +68,19 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     dist = None
+    if args.one_device:
+        if world > 1 and args.backend != "gloo":
+            raise SystemExit("--one-device is a rehearsal mode for --backend gloo")
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the verification path")
     torch.cuda.set_device(local_rank)
@@ -97,7 +106,8 @@ def main():
     assert sv.accept == 1, "synthetic batch is malformed"
 
     verdict = Verdict()
-    flag = torch.ones(1, dtype=torch.int64, device="cuda")
+    on_host = args.backend != "nccl"              # gloo gets host tensors only
+    flag = torch.ones(1, dtype=torch.int64, device="cpu" if on_host else "cuda")
 
     def step(i):
         seed = (i + 1).to_bytes(8, "little") * 4
@@ -129,7 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stages = {k: v / max(stage_n, 1) for k, v in stage_sum.items()}

@@ -7,12 +7,9 @@ namespace xhe {
 
 // ---- sigma proofs ----------------------------------------------------------------------------------
 // gh[2p], gh[2p+1]: this proof's contributions to the scalars of G and H (Montgomery limbs)
-__global__ void __launch_bounds__(256, 2) k_sigma_cm(const u8 *__restrict__ bytes, const dev_cm *__restrict__ cms, const dev_tx *__restrict__ txs, u32 n,
-                                                     const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
-                                                     u32 *__restrict__ term_point, u32 *__restrict__ gh) {
-    wave_priority_high();
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void sigma_cm_terms(u32 i, const u8 *__restrict__ bytes, const dev_cm *__restrict__ cms, const dev_tx *__restrict__ txs,
+                                               const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
+                                               u32 *__restrict__ term_point, u32 *__restrict__ gh) {
     const dev_cm c = cms[i];
     const dev_tx d = txs[c.tx];
     const u8 *p = bytes + c.off;
@@ -37,12 +34,9 @@ __global__ void __launch_bounds__(256, 2) k_sigma_cm(const u8 *__restrict__ byte
     store_sc_limbs(gh + 18ull * i, sc_norm(g));
     store_sc_limbs(gh + 18ull * i + 9, sc_norm(h));
 }
-__global__ void __launch_bounds__(256, 2) k_sigma_xf(const u8 *__restrict__ bytes, const dev_xfer *__restrict__ xfers, const dev_tx *__restrict__ txs, u32 n,
-                                                     const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
-                                                     u32 *__restrict__ term_point, u32 *__restrict__ gh) {
-    wave_priority_high();
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void sigma_xf_terms(u32 i, const u8 *__restrict__ bytes, const dev_xfer *__restrict__ xfers, const dev_tx *__restrict__ txs,
+                                               const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
+                                               u32 *__restrict__ term_point, u32 *__restrict__ gh) {
     const dev_xfer x = xfers[i];
     const dev_tx d = txs[x.tx];
     const u8 *pr = bytes + x.proof_off;
@@ -107,13 +101,10 @@ static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_
                      RPC_Y2 = 37 /* 16 */, RPC_E = 53 /* 16 */;
 static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 
-__global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const dev_cm *__restrict__ cms,
-                                                const dev_xfer *__restrict__ xfers, u32 n_txs, const u32 *__restrict__ chal, const u32 *__restrict__ seed,
-                                                u32 *__restrict__ scalars, u32 *__restrict__ term_point, u32 *__restrict__ rp_ctx, u32 *__restrict__ gh,
-                                                u32 *__restrict__ rp_err) {
-    wave_priority_high();
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_txs) return;
+__device__ __forceinline__ void rp_prep_terms(u32 i, const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const dev_cm *__restrict__ cms,
+                                              const dev_xfer *__restrict__ xfers, const u32 *__restrict__ chal, const u32 *__restrict__ seed,
+                                              u32 *__restrict__ scalars, u32 *__restrict__ term_point, u32 *__restrict__ rp_ctx, u32 *__restrict__ gh,
+                                              u32 *__restrict__ rp_err) {
     const dev_tx d = txs[i];
     const u32 lg = d.lg, A = d.n_commitments, T = d.n_transfers;
     const u32 n_dyn = 4 + 2 * lg + A + T;
@@ -203,6 +194,25 @@ __global__ void __launch_bounds__(64) k_rp_prep(const u8 *__restrict__ bytes, co
     store_sc_limbs(ctx + 9 * RPC_COEF_G, sc_neg(sc_mul(sc_mul(rho_u, yt), a)));
     store_sc_limbs(ctx + 9 * RPC_COEF_H2, sc_mul(sc_mul(rho, UU), zz));
     store_sc_limbs(ctx + 9 * RPC_COEF_H3, sc_neg(sc_mul(rho_u, b)));
+}
+
+// One launch for the scalars of all three proof kinds (they only need the transcript's challenges and are independent
+// of each other): blocks [0, b_cm) take commitment-equality proofs, [b_cm, b_cm + b_xf) ciphertext-validity proofs, the
+// rest one transaction's range proof per thread.  gh[]: per proof / per transaction the contributions to B and H.
+__global__ void __launch_bounds__(64) k_proof_scalars(proof_scalar_args a) {
+    wave_priority_high();
+    const u32 b_cm = (a.n_cm + 63) / 64, b_xf = (a.n_xf + 63) / 64;
+    u32 blk = blockIdx.x;
+    if (blk < b_cm) {
+        u32 i = blk * 64 + threadIdx.x;
+        if (i < a.n_cm) sigma_cm_terms(i, a.bytes, a.cms, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh);
+    } else if (blk < b_cm + b_xf) {
+        u32 i = (blk - b_cm) * 64 + threadIdx.x;
+        if (i < a.n_xf) sigma_xf_terms(i, a.bytes, a.xfers, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh + 18ull * a.n_cm);
+    } else {
+        u32 i = (blk - b_cm - b_xf) * 64 + threadIdx.x;
+        if (i < a.n_txs) rp_prep_terms(i, a.bytes, a.txs, a.cms, a.xfers, a.chal, a.seed, a.scalars, a.term_point, a.rp_ctx, a.gh + 18ull * (a.n_cm + a.n_xf), a.rp_err);
+    }
 }
 
 // Workgroup per tile of rows_per_thread transactions of the lg-group: partial column sums of the scalars of
@@ -339,19 +349,12 @@ __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh
 }
 
 
-void launch_sigma_cm(hipStream_t st, const u8 *bytes, const dev_cm *cms, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point, u32 *gh) {
-    if (n) hipLaunchKernelGGL(k_sigma_cm, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, cms, txs, n, chal, seed, scalars, term_point, gh);
-}
-void launch_sigma_xf(hipStream_t st, const u8 *bytes, const dev_xfer *xfers, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point,
-                     u32 *gh) {
-    if (n) hipLaunchKernelGGL(k_sigma_xf, dim3(grid_for(n, 256)), dim3(256), 0, st, bytes, xfers, txs, n, chal, seed, scalars, term_point, gh);
+void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a) {
+    u32 blocks = (a.n_cm + 63) / 64 + (a.n_xf + 63) / 64 + (a.n_txs + 63) / 64;
+    if (blocks) hipLaunchKernelGGL(k_proof_scalars, dim3(blocks), dim3(64), 0, st, a);
 }
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out) {
     hipLaunchKernelGGL(k_sc_sum_partial, dim3(blocks), dim3(256), 0, st, in, n, classes, out);
-}
-void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *chal, const u32 *seed, u32 *scalars,
-                    u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err) {
-    if (n_txs) hipLaunchKernelGGL(k_rp_prep, dim3(grid_for(n_txs, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, n_txs, chal, seed, scalars, term_point, rp_ctx, gh, rp_err);
 }
 void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part) {
     if (!n_rows || !rows_per_thread) return;

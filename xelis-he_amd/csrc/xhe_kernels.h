@@ -81,12 +81,13 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
 void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts);
 // proof scalars
 static constexpr u32 RPC_SCALARS = 69;    // Montgomery-limb scalars in a transaction's range-proof context
-void launch_sigma_cm(hipStream_t st, const u8 *bytes, const dev_cm *cms, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point, u32 *gh);
-void launch_sigma_xf(hipStream_t st, const u8 *bytes, const dev_xfer *xfers, const dev_tx *txs, u32 n, const u32 *chal, const u32 *seed, u32 *scalars, u32 *term_point,
-                     u32 *gh);
+// sigma-proof terms, range-proof terms and the per-transaction range-proof context in one launch
+struct proof_scalar_args {
+    const u8 *bytes; const dev_tx *txs; const dev_cm *cms; const dev_xfer *xfers; u32 n_cm, n_xf, n_txs;
+    const u32 *chal, *seed; u32 *scalars, *term_point, *rp_ctx, *gh, *rp_err;
+};
+void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a);
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out);
-void launch_rp_prep(hipStream_t st, const u8 *bytes, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u32 *chal, const u32 *seed, u32 *scalars,
-                    u32 *term_point, u32 *rp_ctx, u32 *gh, u32 *rp_err);
 // A workgroup takes rows_per_thread transactions of an lg-group, rp_matrix_slots(lg) of them side by side, and writes one row of
 // partial column sums per slot: part[ceil(n_rows / rows_per_thread) * slots][2 * 2^lg], summed by launch_rp_colsum
 XHE_HD u32 rp_matrix_slots(u32 lg) { return lg >= 8 ? 1u : 256u >> lg; }

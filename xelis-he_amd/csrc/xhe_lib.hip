@@ -531,12 +531,12 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.close("signatures", s1));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
-    // main: proof scalars
-    HIPCHK(ctx, tm.mark("sigma_scalars", st));
-    launch_sigma_cm(st, bytes, cms, txs, n_cm, chal, sd, scalars, term_point, gh);
-    launch_sigma_xf(st, bytes, xfers, txs, n_xf, chal, sd, scalars, term_point, gh + 18ull * n_cm);
-    HIPCHK(ctx, tm.mark("rangeproof_scalars", st));
-    launch_rp_prep(st, bytes, txs, cms, xfers, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh + 18ull * (n_cm + n_xf), rp_err);
+    // main: proof scalars (sigma terms, range-proof terms, per-transaction range-proof context)
+    HIPCHK(ctx, tm.mark("proof_scalars", st));
+    {
+        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
+        launch_proof_scalars(st, pa);
+    }
     // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
     // parts).  With fixed-base tables their whole contribution is evaluated on side 0 while the main stream
     // sorts and accumulates the dynamic terms; without, they join the multiscalar check as terms.
