@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) k_proof_scalars(proof_scalar_args a) {
 // the bits of i are needed (s_i, its mirror times y^-i, z^j 2^k y^-i).  A product over the bits of i is the
 // product of one factor for the low bits and one for the high bits, so the workgroup first fills, per
 // transaction, two small tables per product in LDS (2^l + 2^h entries, l + h = lg) and every element then costs
-// three multiplications instead of 2.5 lg.  (Products: see the table above k_rp_prep.)
+// three multiplications instead of 2.5 lg.  (Products: see the table above rp_prep_terms.)
 static constexpr u32 RPM_THREADS = 256;
 // Groups with fewer than 256 generators per side run 256 >> lg transactions side by side ("slots"), each slot
 // writing its own row of part[]; larger groups give every thread several indices.
