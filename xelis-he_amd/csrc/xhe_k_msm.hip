@@ -527,7 +527,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
                        ws.buckets, ws.chunk_sums);
     MARK("msm_merge");
     hipLaunchKernelGGL(k_msm_merge, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.offsets, (u32)n_buckets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
-    hipLaunchKernelGGL(k_msm_merge_big, dim3(big_cap < 64 ? big_cap : 64), dim3(256), 0, st, ws.offsets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
+    hipLaunchKernelGGL(k_msm_merge_big, dim3(big_cap < 2048 ? big_cap : 2048), dim3(256), 0, st, ws.offsets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
     MARK("msm_reduce");
     hipLaunchKernelGGL(k_msm_reduce_segments, dim3(p.W * p.S), dim3(64), 0, st, ws.buckets, p, ws.segs);
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);

@@ -16,6 +16,9 @@
 namespace xhe {
 
 static constexpr u32 SIG_RATE_WORDS = 9;      // SHA3-512: 72-byte rate
+// The signatures run in the background of the main path: at most one wavefront per SIMD of each kernel stays resident
+// (grid-stride beyond that), so that their registers never keep a main-path workgroup from being placed.
+static constexpr u32 SIG_MAX_WAVES = 1024;
 
 // byte j of pk || msg (msg = the digest for a co-signature)
 struct sig_stream {
@@ -32,8 +35,7 @@ __device__ __forceinline__ u32 sig_whole_blocks(const dev_sig &sg) { return sg.h
 
 // state[w * n + i]: word w of signature i's sponge after its whole blocks
 __global__ void __launch_bounds__(64) k_sig_absorb(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, u64 *__restrict__ state) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const dev_sig sg = sigs[i];
     const u32 nb = sig_whole_blocks(sg);
     const u8 *key = bytes + sg.key_off, *msg = bytes + sg.msg_off;
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(64) k_sig_absorb(const u8 *__restrict__ bytes,
     }
 #pragma unroll
     for (int w = 0; w < 25; w++) state[(u64)w * n + i] = a[w];
+    }
 }
 
 // ---- R = s*H - e*P on a quad of lanes ---------------------------------------------------------------
@@ -86,7 +89,8 @@ __global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, 
                                                   const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
     __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
     const u32 lane = threadIdx.x, role = lane & 3;
-    const u32 q = blockIdx.x * SIG_QUADS + (lane >> 2);
+    for (u32 group = blockIdx.x; group * SIG_QUADS < n; group += gridDim.x) {
+    const u32 q = group * SIG_QUADS + (lane >> 2);
     const u32 i = q < n ? q : n - 1;           // spare quads repeat the last signature and store nothing
     const dev_sig sg = sigs[i];
     u32 sw[8], ew[8];
@@ -139,6 +143,7 @@ __global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, 
     }
     R = qd_add_cached(R, qd_to_cached(Q, role), true, role);
     if (q < n) qd_store(r_out + 32ull * q, R, role);
+    }
 }
 
 __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u64 *__restrict__ state,
@@ -183,10 +188,12 @@ __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, 
 }
 
 void launch_sig_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, u64 *state) {
-    if (n) hipLaunchKernelGGL(k_sig_absorb, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state);
+    u32 blocks = grid_for(n, 64);
+    if (n) hipLaunchKernelGGL(k_sig_absorb, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, bytes, sigs, n, state);
 }
 void launch_sig_point(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u32 *htab, u32 *r_out) {
-    if (n) hipLaunchKernelGGL(k_sig_point, dim3(grid_for(n, SIG_QUADS)), dim3(64), 0, st, bytes, sigs, n, pts, htab, r_out);
+    u32 blocks = grid_for(n, SIG_QUADS);
+    if (n) hipLaunchKernelGGL(k_sig_point, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, bytes, sigs, n, pts, htab, r_out);
 }
 void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err) {
     if (n) hipLaunchKernelGGL(k_sig_final, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state, r_in, ok, ms_hash, tx_err);
