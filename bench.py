@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--txs", type=int, default=10000, help="transactions per GPU batch")
     ap.add_argument("--transfers", type=int, default=1)
+    ap.add_argument("--workload", choices=["transfers", "mixed"], default="transfers",
+                    help="mixed: groups of 16 transactions (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers)")
     ap.add_argument("--senders", type=int, default=1024, help="sender accounts per batch (1 = the reference bench's single chain)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="transactions of the batch the CPU baseline verifies (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=16)
@@ -94,7 +96,10 @@ def main():
 
     t0 = time.time()
     senders = min(args.senders, args.txs)
-    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads)
+    mixed = args.workload == "mixed"
+    if mixed:
+        args.txs -= args.txs % 16
+    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed)
     gen_s = time.time() - t0
 
     handle = ctypes.c_void_p()
@@ -159,6 +164,11 @@ def main():
     lg = 6 + (m.bit_length() - 1)
     dyn_terms = args.txs * (7 * A + 8 * T + 4 + 2 * lg + A + T)
     static_terms = 2 + 2 * 64 * m
+    if mixed:
+        # per group of 16: 2 set-ups (24 terms), 4 one-asset transfers (35), 4 two-asset double transfers (54), 2 native burns (24),
+        # 2 second-asset burns (34), 2 co-signed transfers (35); four value commitments at most -> 256 generators per side
+        dyn_terms = (args.txs // 16) * (2 * 24 + 4 * 35 + 4 * 54 + 2 * 24 + 2 * 34 + 2 * 35)
+        static_terms = 2 + 2 * 256
     algo_bytes = (dyn_terms + static_terms) * 160 + 32
     acc_ms = stages.get("msm_accumulate", 0.0)
     roofline = None
@@ -188,7 +198,8 @@ def main():
             "metric": "verified tx/sec (batched)", "value": round(total_txs / elapsed, 1), "unit": "tx/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
+            "config": {"workload": ("%d-tx mixed batch per GPU (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers), %d account groups" % (args.txs, args.txs // 16)) if mixed
+                       else "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
                        "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},

@@ -66,6 +66,9 @@ int32_t xhe_tx_apply_host(const uint8_t *record, uint64_t len, uint64_t n_accoun
 
 typedef struct xhe_synth xhe_synth;
 xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads);
+/* n_groups x 16 mixed transactions over disjoint account groups: 2 multisig set-ups, 4 one-asset transfers, 4 two-asset
+ * double transfers, 2 native + 2 second-asset burns, 2 co-signed transfers from the accounts set up in the same group. */
+xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads);
 void xhe_synth_free(xhe_synth *s);
 const uint8_t *xhe_synth_records(const xhe_synth *s, uint64_t *len);
 const uint64_t *xhe_synth_offsets(const xhe_synth *s, uint64_t *n_txs);

@@ -295,3 +295,34 @@ def test_synthetic_batch(engine, oracle):
     oracle.xo_verify_batch(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, ctypes.byref(ref_out), ctypes.byref(rv), b"\x02" * 32)
     assert rv.accept == 1
     assert bytes(out_cts) == bytes(ref_cts)
+
+
+def _raw_verify(lib, fn_owner, ctx, sb, records=None):
+    n_bal, n_acc = sb.view.contents.n_balances, sb.view.contents.n_accounts
+    cts = (ctypes.c_uint8 * (64 * n_bal))()
+    ms = (ctypes.c_int64 * n_acc)()
+    out = LedgerOut(cts, (ctypes.c_uint64 * n_acc)(), ms)
+    v = Verdict()
+    recs = sb.records if records is None else records
+    if ctx is None:
+        fn_owner.xo_verify_batch(recs, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, ctypes.byref(out), ctypes.byref(v), b"\x02" * 32)
+    else:
+        fn_owner._check(lib.xhe_verify_batch(ctx, recs, sb.offsets, sb.n_txs, sb.view, ctypes.byref(out), ctypes.byref(v), b"\x01" * 32))
+    return (v.accept, v.err_code, v.first_bad_tx), bytes(cts), list(ms)
+
+
+def test_mixed_synthetic_batch(engine, oracle):
+    """The mixed workload (multisig set-ups and their use in one batch, two-asset transactions, burns): verdict, ledger
+    bytes and multisig bookkeeping equal the oracle's; a broken co-signature and a broken burn are found at their index."""
+    sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)
+    got, cts, ms = _raw_verify(engine.lib, engine, engine.ctx, sb)
+    ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb)
+    assert got == ref == (1, codes.OK, -1)
+    assert cts == ref_cts and ms == ref_ms
+    offs = list(sb.offsets)
+    for tx, back in [(16 * 3 + 14, 64 + 65 + 10), (16 * 9 + 11, 64 + 256 + 300), (16 * 15 + 0, 64 + 10)]:
+        bad = bytearray(sb.records)
+        bad[offs[tx + 1] - back] ^= 1              # a co-signature / the range proof of a burn / a commitment proof scalar of a set-up
+        g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
+        r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
+        assert g == r and g[0] == 0 and g[2] == tx, (tx, g, r)

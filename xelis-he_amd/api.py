@@ -83,6 +83,8 @@ def _lib():
                                              ctypes.POINTER(LedgerView), ctypes.POINTER(LedgerOut), ctypes.POINTER(Verdict), ctypes.c_char_p]
         lib.xhe_synth_transfers.restype = ctypes.c_void_p
         lib.xhe_synth_transfers.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32]
+        lib.xhe_synth_mixed.restype = ctypes.c_void_p
+        lib.xhe_synth_mixed.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_free.argtypes = [ctypes.c_void_p]
         lib.xhe_synth_records.restype = ctypes.c_void_p
         lib.xhe_synth_records.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -402,10 +404,17 @@ class TransactionBuilder:
 class SyntheticBatch:
     """benches/tx.rs:129-189 generalised: n_txs transfer transactions over n_senders sender/receiver pairs."""
 
-    def __init__(self, n_txs, n_transfers=1, n_senders=1, seed=b"synthetic", threads=None):
+    def __init__(self, n_txs, n_transfers=1, n_senders=1, seed=b"synthetic", threads=None, mixed=False):
+        """mixed=True: n_txs / 16 groups of mixed transactions (multisig set-ups, one- and two-asset transfers, burns,
+        co-signed transfers) over disjoint account groups; n_transfers and n_senders are ignored."""
         lib = _lib()
         threads = threads or min(os.cpu_count() or 1, 16)
-        self.handle = lib.xhe_synth_transfers(n_txs, n_transfers, n_senders, _fresh_seed(seed), threads)
+        if mixed:
+            if n_txs % 16:
+                raise ValueError("a mixed batch is made of groups of 16 transactions")
+            self.handle = lib.xhe_synth_mixed(n_txs // 16, _fresh_seed(seed), threads)
+        else:
+            self.handle = lib.xhe_synth_transfers(n_txs, n_transfers, n_senders, _fresh_seed(seed), threads)
         if not self.handle:
             raise XheError("synthetic batch generation failed")
         n = ctypes.c_uint64()

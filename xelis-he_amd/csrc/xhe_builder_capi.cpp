@@ -239,6 +239,105 @@ xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_
     v.n_balances = 2ull * n_senders; v.balance_account = S->balance_account.data(); v.balance_assets = S->balance_assets.data(); v.balance_cts = S->balance_cts.data();
     return S;
 }
+// n_groups groups of 16 transactions over disjoint account sets: two multisig set-ups (2 signers, threshold 2), four
+// one-transfer transactions, four with a native and a second-asset transfer (two source commitments, four value
+// commitments), two native and two second-asset burns, and a co-signed transfer from each of the two multisig
+// accounts configured earlier in the same group.  Accounts per group: sender (both assets), receiver (both assets),
+// two multisig accounts, two co-signers.  Every transaction is built on the ledger left by its predecessors.
+xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads) {
+    if (!n_groups || !seed32) return nullptr;
+    if (threads < 1) threads = 1;
+    xhe_synth *S = new xhe_synth();
+    drbg root(seed32);
+    const u64 FUNDS = 1000000, ACC = 6, SLOTS = 8, TXS = 16;
+    bytes32 asset2; asset2.fill(55);
+    struct group_keys { keypair k[6]; };
+    std::vector<group_keys> keys(n_groups);
+    S->account_keys.resize(32 * ACC * n_groups); S->nonces.assign(ACC * n_groups, 0);
+    S->balance_account.resize(SLOTS * n_groups); S->balance_assets.assign(32 * SLOTS * n_groups, 0); S->balance_cts.resize(64 * SLOTS * n_groups);
+    S->secrets.resize(32 * ACC * n_groups);
+    // slot layout per group: 0 sender/native, 1 sender/asset2, 2 receiver/native, 3 receiver/asset2, 4 multisig0, 5 multisig1, 6 cosigner0, 7 cosigner1
+    const u32 slot_acc[8] = {0, 0, 1, 1, 2, 3, 4, 5};
+    const bool slot_second[8] = {false, true, false, true, false, false, false, false};
+    const u64 slot_funds[8] = {FUNDS, FUNDS, 0, 0, FUNDS, FUNDS, 0, 0};
+    for (u64 g = 0; g < n_groups; g++) {
+        for (u32 a = 0; a < ACC; a++) {
+            keys[g].k[a] = keypair::from_secret(root.scalar());
+            sc_tobytes(&S->secrets[32 * (ACC * g + a)], keys[g].k[a].secret);
+            memcpy(&S->account_keys[32 * (ACC * g + a)], keys[g].k[a].pub_bytes.data(), 32);
+        }
+        for (u32 sl = 0; sl < SLOTS; sl++) {
+            u64 i = SLOTS * g + sl;
+            S->balance_account[i] = (u32)(ACC * g + slot_acc[sl]);
+            if (slot_second[sl]) memcpy(&S->balance_assets[32 * i], asset2.data(), 32);
+            bytes64 ct = ct_bytes(encrypt(keys[g].k[slot_acc[sl]].pub, slot_funds[sl], root.scalar()));
+            memcpy(&S->balance_cts[64 * i], ct.data(), 64);
+        }
+    }
+    std::vector<std::vector<u8>> recs(TXS * n_groups);
+    std::vector<bytes32> seeds(n_groups);
+    for (u64 g = 0; g < n_groups; g++) { u8 t[32]; root.bytes(t, 32); seeds[g] = b32(t); }
+    std::atomic<u64> next_group(0); std::atomic<int> failed(0);
+    auto worker = [&]() {
+        for (;;) {
+            u64 g = next_group.fetch_add(1);
+            if (g >= n_groups) break;
+            drbg rng(seeds[g].data());
+            const keypair *k = keys[g].k;
+            // the prover's view of the balances it spends from: sender native / second asset, multisig 0 / 1
+            asset_balance sn{bytes32{}, FUNDS, {}}, s2{asset2, FUNDS, {}}, m0{bytes32{}, FUNDS, {}}, m1{bytes32{}, FUNDS, {}};
+            memcpy(sn.ct.data(), &S->balance_cts[64 * (SLOTS * g + 0)], 64); memcpy(s2.ct.data(), &S->balance_cts[64 * (SLOTS * g + 1)], 64);
+            memcpy(m0.ct.data(), &S->balance_cts[64 * (SLOTS * g + 4)], 64); memcpy(m1.ct.data(), &S->balance_cts[64 * (SLOTS * g + 5)], 64);
+            auto build = [&](builder_in &in, const keypair &src, std::vector<asset_balance *> bal, bool cosign) -> std::vector<u8> {
+                for (auto *b : bal) in.balances.push_back(*b);
+                unsigned_tx u; std::vector<asset_balance> nb;
+                if (build_unsigned(in, src, rng, u, &nb) != BUILD_OK) { failed = 1; return {}; }
+                for (auto &n : nb) for (auto *b : bal) if (b->asset == n.asset) *b = n;
+                if (cosign) {
+                    bytes32 h = u.hash();
+                    u.has_multisig = true;
+                    for (u8 c = 0; c < 2; c++) u.multisig.push_back({c, host::sign(k[4 + c], h.data(), 32, rng)});
+                }
+                return u.sign(src, rng);
+            };
+            auto transfer = [&](const bytes32 &asset) { transfer_in tr; tr.asset = asset; tr.amount = 1; tr.dest = k[1].pub_bytes; return tr; };
+            u64 base = TXS * g;
+            for (u32 j = 0; j < 2; j++) {             // multisig set-ups
+                builder_in in; in.type = 2; in.fee = 3; in.signers = {k[4].pub_bytes, k[5].pub_bytes}; in.threshold = 2;
+                recs[base + j] = build(in, k[2 + j], {j ? &m1 : &m0}, false);
+            }
+            for (u32 j = 0; j < 4; j++) {             // one transfer, one asset
+                builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{})};
+                recs[base + 2 + j] = build(in, k[0], {&sn}, false);
+            }
+            for (u32 j = 0; j < 4; j++) {             // two transfers, two assets
+                builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{}), transfer(asset2)};
+                recs[base + 6 + j] = build(in, k[0], {&sn, &s2}, false);
+            }
+            for (u32 j = 0; j < 4; j++) {             // burns: native, native, second asset, second asset
+                builder_in in; in.type = 1; in.fee = 3; in.burn_asset = j < 2 ? bytes32{} : asset2; in.burn_amount = 1;
+                recs[base + 10 + j] = j < 2 ? build(in, k[0], {&sn}, false) : build(in, k[0], {&sn, &s2}, false);
+            }
+            for (u32 j = 0; j < 2; j++) {             // co-signed transfers from the multisig accounts
+                builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{})};
+                recs[base + 14 + j] = build(in, k[2 + j], {j ? &m1 : &m0}, true);
+            }
+            if (failed) return;
+        }
+    };
+    gens().ensure(64 * 4);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+    for (auto &th : pool) th.join();
+    if (failed) { delete S; return nullptr; }
+    S->offsets.push_back(0);
+    for (auto &r : recs) { S->records.insert(S->records.end(), r.begin(), r.end()); S->offsets.push_back(S->records.size()); }
+    xhe_ledger_view &v = S->view;
+    memset(&v, 0, sizeof v);
+    v.n_accounts = ACC * n_groups; v.account_keys = S->account_keys.data(); v.account_nonces = S->nonces.data();
+    v.n_balances = SLOTS * n_groups; v.balance_account = S->balance_account.data(); v.balance_assets = S->balance_assets.data(); v.balance_cts = S->balance_cts.data();
+    return S;
+}
 void xhe_synth_free(xhe_synth *s) { delete s; }
 const uint8_t *xhe_synth_records(const xhe_synth *s, uint64_t *len) { if (len) *len = s->records.size(); return s->records.data(); }
 const uint64_t *xhe_synth_offsets(const xhe_synth *s, uint64_t *n_txs) { if (n_txs) *n_txs = s->offsets.size() - 1; return s->offsets.data(); }
