@@ -134,3 +134,29 @@ def test_transcript_template_matches_transcript(oracle, hostlib):
             assert zeros.value == 0 and blocks.value > 10
             seen += 1
     assert seen >= 15
+
+
+def test_ingest_layout_counts(hostlib):
+    """Host ingest (xhe_ingest.h) of synthetic batches on the CPU: the sizes of the tables it lays out for the kernels
+    follow from the batch's shape (terms of the merged multiscalar check, challenges, signatures, transcript tiles)."""
+    import ctypes
+    from xelis_he_amd.api import SyntheticBatch
+    hostlib.xt_ingest.restype = ctypes.c_double
+    cnt = (ctypes.c_uint64 * 8)()
+    for n, t in [(96, 1), (40, 3)]:
+        sb = SyntheticBatch(n, n_transfers=t, n_senders=8, seed=b"ingest-%d" % t, threads=4)
+        assert hostlib.xt_ingest(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, cnt) >= 0
+        ok, n_points, n_terms, n_sigs, n_ops, n_tiles, n_chal, stream_words = list(cnt)
+        m = 1
+        while m < 1 + t:
+            m *= 2
+        lg = 6 + m.bit_length() - 1
+        assert ok == 1 and n_sigs == n and n_tiles == (n + 63) // 64
+        assert n_terms == n * (7 + 8 * t + 4 + 2 * lg + 1 + t) + 2 + 2 * 64 * m
+        assert n_chal == n * (2 + 2 * t + 4 + lg)
+        # per transaction: initial balance (first touch only), t transfers out, the closing fee/emit op; t receiver credits
+        assert n_ops >= n * (t + 1 + t) and stream_words % (21 * 64) == 0
+    sb = SyntheticBatch(32, seed=b"ingest-mixed", mixed=True, threads=4)
+    assert hostlib.xt_ingest(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, cnt) >= 0
+    assert cnt[0] == 1 and cnt[3] == 32 + 2 * 2 * 2 and cnt[2] == 2 * 590 + 2 + 2 * 256      # co-signatures: 2 per co-signed transfer
+    assert cnt[5] >= 5                                    # one transcript tile per shape at least

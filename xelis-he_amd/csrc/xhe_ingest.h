@@ -21,9 +21,17 @@
 
 namespace xhe {
 
-struct key32_hash {
-    size_t operator()(const std::string &s) const { size_t h; memcpy(&h, s.data(), sizeof h); return h; }
+// fixed-size byte keys for the ledger look-ups (public keys are uniformly distributed: their first bytes are the hash)
+template <size_t N> struct byte_key {
+    u8 b[N];
+    bool operator==(const byte_key &o) const { return !memcmp(b, o.b, N); }
 };
+template <size_t N> struct byte_key_hash {
+    size_t operator()(const byte_key<N> &k) const { u64 h, t; memcpy(&h, k.b, 8); memcpy(&t, k.b + N - 8, 8); return (size_t)(h ^ (t * 0x9e3779b97f4a7c15ull)); }
+};
+typedef byte_key<32> key32;
+typedef byte_key<36> key36;          // asset(32) || account index(4)
+static inline key32 make_key32(const u8 *p) { key32 k; memcpy(k.b, p, 32); return k; }
 
 struct host_batch {
     u64 n_txs = 0;
@@ -94,12 +102,12 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     if (n_signers) memcpy(hb.bytes.data() + hb.signers_base, lv.multisig_signers, 32 * n_signers);
 
     // ---- ledger key structure ----
-    std::unordered_map<std::string, u32, key32_hash> account_of;
+    std::unordered_map<key32, u32, byte_key_hash<32>> account_of;
     account_of.reserve(lv.n_accounts * 2 + 16);
-    for (u64 i = 0; i < lv.n_accounts; i++) account_of.emplace(std::string((const char *)lv.account_keys + 32 * i, 32), (u32)i);
-    std::unordered_map<std::string, u32, key32_hash> slot_of;      // key = asset(32) || account idx(4)
+    for (u64 i = 0; i < lv.n_accounts; i++) account_of.emplace(make_key32(lv.account_keys + 32 * i), (u32)i);
+    std::unordered_map<key36, u32, byte_key_hash<36>> slot_of;
     slot_of.reserve(lv.n_balances * 2 + 16);
-    auto slot_key = [](const u8 *asset, u32 account) { std::string k((const char *)asset, 32); k.append((const char *)&account, 4); return k; };
+    auto slot_key = [](const u8 *asset, u32 account) { key36 k; memcpy(k.b, asset, 32); memcpy(k.b + 32, &account, 4); return k; };
     for (u64 i = 0; i < lv.n_balances; i++) slot_of.emplace(slot_key(lv.balance_assets + 32 * i, lv.balance_account[i]), (u32)i);
     struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
     std::unordered_map<u32, ms_cfg> ms_of;
@@ -140,6 +148,17 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     };
 
     hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE);
+    {
+        // sizes are known from the parsed records up to the ledger's first-touch points: reserve once
+        u64 n_xf = 0, n_cm = 0, n_pts = 0, n_ms = 0;
+        for (u64 i = 0; i < n; i++) {
+            u64 T = recs[i].transfer_off.size(), A = recs[i].n_commitments;
+            n_xf += T; n_cm += A; n_ms += recs[i].n_multisig; n_pts += 4 + 2ull * recs[i].lg() + 6 * T + 4 * A + 1;
+        }
+        n_pts += 2 * n_xf + 2 * n_cm;                  // ledger ciphertexts touched for the first time, receiver keys
+        hb.decs.reserve(n_pts); hb.rp_dec_tx.reserve(n_pts); hb.early_decs.reserve(5 * n_xf + 2 * n_cm); hb.key_decs.reserve(n + n_xf);
+        hb.cms.reserve(n_cm); hb.xfers.reserve(n_xf); hb.sigs.reserve(n + n_ms); hb.segs.reserve(2 * n + n_cm + 2 * n_xf);
+    }
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_of;
     hb.lg_groups.assign(16, {});
     u32 term = 0, chal = 0;
@@ -181,7 +200,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         for (u32 k = 0; k < 2 * lg; k++) new_point(rec + t.rp_off + 224 + 32 * k, (u32)i);
 
         // source account, nonce (verify.rs:210-221)
-        auto acc_it = account_of.find(std::string((const char *)t.source(), 32));
+        auto acc_it = account_of.find(make_key32(t.source()));
         bool src_known = acc_it != account_of.end();
         u32 src_acc = src_known ? acc_it->second : 0;
         if (!src_known) raise(i, errkey(ST_NONCE, 0, 0, XHE_ERR_STATE));
@@ -261,7 +280,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             x.pt = xf_pt[k];
             x.term_off = xf_term[i] + 8 * k;
             const u8 *asset = t.transfer(k), *dest = t.transfer(k) + 32;
-            auto da = account_of.find(std::string((const char *)dest, 32));
+            auto da = account_of.find(make_key32(dest));
             if (da == account_of.end()) {
                 x.dest_pt = new_point(x.off + 32, 0xffffffffu);
                 x.state_err = 1;
