@@ -38,7 +38,7 @@ msm_plan msm_make_plan(u64 n) {
     else c = 15;                                     // a digit is kept in 15 bits + sign
     msm_plan p;
     p.c = c; p.W = (252 + c - 1) / c; p.B = 1u << (c - 1);          // recoded scalars are below 2^252
-    u32 L = p.B / 4096; if (L < 1) L = 1;          // S = B/(64L) <= 64
+    u32 L = p.B / 2048; if (L < 1) L = 1;          // S = B/(64L) <= 32: W*S wavefronts, at most one per SIMD
     if (p.B < 64) L = 1;
     p.L = L; p.S = (p.B + 64 * L - 1) / (64 * L);
     // entries per accumulate chunk: about half a bucket's expected load (few buckets are cut into more than a handful of
