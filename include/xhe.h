@@ -134,6 +134,13 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
                          const xhe_ledger_view *in, xhe_batch **batch_out, xhe_verdict *structural_verdict);
 int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *batch, xhe_verdict *verdict, const uint8_t rng_seed[32]);
 int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *batch, const xhe_ledger_out *out);
+/* Transaction::apply_without_verify (/root/reference/src/tx/verify.rs:545-619) for every transaction of the uploaded
+ * batch in order: only the Twisted-ElGamal ledger arithmetic (sender balance minus fee/burn/deposits and transfer
+ * ciphertexts, receiver balance plus transfer ciphertext, elgamal.rs:280-377), no signature, nonce or proof check.
+ * On accept xhe_batch_read_ledger returns the resulting ledger.  Where the reference returns the state's error or
+ * panics ("ill-formed ciphertext"), the verdict is XHE_ERR_STATE / XHE_ERR_DECOMPRESSION with the transaction's index.
+ * multisig_set_by reports MultiSig transactions with a well-formed payload only. */
+int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *batch, xhe_verdict *verdict);
 void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
 
 /* Per-stage GPU time of the last xhe_batch_verify / xhe_msm_vartime on this context, measured with HIP

@@ -326,3 +326,66 @@ def test_mixed_synthetic_batch(engine, oracle):
         g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
         r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
         assert g == r and g[0] == 0 and g[2] == tx, (tx, g, r)
+
+
+def test_apply_without_verify_batch(engine, oracle):
+    """xhe_batch_apply (the ledger scan alone) against the host's apply_without_verify run transaction by transaction,
+    and against the ledger an accepting verify_batch leaves; unknown receivers and broken ciphertexts are reported."""
+    bob = Account([(NATIVE, 100), (ASSET55, 2)], "ap-bob")
+    alice = Account([(NATIVE, 0), (ASSET55, 0)], "ap-alice")
+    eve = Account([(NATIVE, 52), (ASSET55, 0)], "ap-eve")
+    ledger = Ledger([bob, alice, eve])
+    tx1 = TransactionBuilder(1, bob.pubkey, ("transfers", [TransferBuilder(alice.pubkey, 52), TransferBuilder(eve.pubkey, 4),
+                                                            TransferBuilder(eve.pubkey, 2, ASSET55)]), 1, 0).build(
+        {NATIVE: 100, ASSET55: 2}, bob.keypair, "ap1", bob)
+    after1 = ledger.clone()
+    tx1.apply_without_verify(after1)
+    tx2 = TransactionBuilder(1, alice.pubkey, ("transfers", [TransferBuilder(eve.pubkey, 30)]), 1, 0).build(
+        {NATIVE: 52}, alice.keypair, "ap2", after1.get_account(alice.pubkey))
+    tx3 = TransactionBuilder(1, eve.pubkey, ("burn", NATIVE, 7), 2, 0).build({NATIVE: 52}, eve.keypair, "ap3", eve)
+    txs = [tx1, tx2, tx3]
+    host = ledger.clone()
+    for t in txs:
+        t.apply_without_verify(host)
+    gpu = ledger.clone()
+    Transaction.apply_batch(engine, txs, gpu)
+    verified = ledger.clone()
+    Transaction.verify_batch(engine, [tx1, tx2], verified, seed="ap")
+    for k, a in host.accounts.items():
+        assert gpu.accounts[k].balances == a.balances
+    assert gpu.balance_decrypts_to(eve.pubkey, NATIVE, 52 + 4 + 30 - 9) and gpu.balance_decrypts_to(bob.pubkey, NATIVE, 43)
+    assert verified.accounts[alice.pubkey].balances == gpu.accounts[alice.pubkey].balances
+    # apply does not check proofs or signatures: a transaction with a zeroed signature still applies
+    forged = _mutate(tx3, len(tx3.record) - 64, bytes(64))
+    again = ledger.clone()
+    Transaction.apply_batch(engine, [tx1, tx2, forged], again)
+    assert again.accounts[eve.pubkey].balances == host.accounts[eve.pubkey].balances
+    # unknown receiver -> State at its index; broken transfer ciphertext -> Decompression
+    with pytest.raises(VerificationError) as e:
+        Transaction.apply_batch(engine, txs, Ledger([bob, alice]))
+    assert e.value.code == codes.ERR_STATE and e.value.first_bad_tx == 0
+    bad = _mutate(tx2, 16 + 4 + 49 + 64, bytes([0xff]) * 32)
+    with pytest.raises(VerificationError) as e:
+        Transaction.apply_batch(engine, [tx1, bad], ledger.clone())
+    assert e.value.code == codes.ERR_DECOMPRESSION and e.value.first_bad_tx == 1
+    # a larger chained batch: equal to the ledger verify_batch produces
+    sb = SyntheticBatch(256, n_transfers=2, n_senders=16, seed=b"apply-256")
+    lib = engine.lib
+    lib.xhe_batch_upload.restype = lib.xhe_batch_apply.restype = lib.xhe_batch_read_ledger.restype = ctypes.c_int32
+    n_bal, n_acc = sb.view.contents.n_balances, sb.view.contents.n_accounts
+    res = []
+    for mode in ("apply", "verify"):
+        h, v = ctypes.c_void_p(), Verdict()
+        ctx = ctypes.c_void_p(engine.ctx)
+        engine._check(lib.xhe_batch_upload(ctx, sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, ctypes.byref(h), ctypes.byref(v)))
+        if mode == "apply":
+            engine._check(lib.xhe_batch_apply(ctx, h, ctypes.byref(v)))
+        else:
+            engine._check(lib.xhe_batch_verify(ctx, h, ctypes.byref(v), b"\x05" * 32))
+        assert v.accept == 1
+        cts = (ctypes.c_uint8 * (64 * n_bal))()
+        out = LedgerOut(cts, (ctypes.c_uint64 * n_acc)(), (ctypes.c_int64 * n_acc)())
+        engine._check(lib.xhe_batch_read_ledger(ctx, h, ctypes.byref(out)))
+        lib.xhe_batch_free(ctx, h)
+        res.append(bytes(cts))
+    assert res[0] == res[1]

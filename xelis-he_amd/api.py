@@ -280,6 +280,38 @@ class Transaction:
             raise VerificationError(v.err_code, v.first_bad_tx)
         ledger.absorb(f, bytes(out_cts), list(out_nonces), list(ms_set), txs)
 
+    @staticmethod
+    def apply_batch(engine, txs, ledger: Ledger):
+        """Transaction::apply_without_verify (verify.rs:545-619) for every transaction in order, on the GPU (the ledger
+        scan alone).  Mutates `ledger`; raises VerificationError for an unknown account/asset or an ill-formed ciphertext."""
+        lib = _lib()
+        f = ledger.flatten()
+        blob = b"".join(t.record for t in txs)
+        offs = [0]
+        for t in txs:
+            offs.append(offs[-1] + len(t.record))
+        offsets = (ctypes.c_uint64 * len(offs))(*offs)
+        handle = ctypes.c_void_p()
+        v = Verdict()
+        lib.xhe_batch_upload.restype = ctypes.c_int32
+        lib.xhe_batch_apply.restype = ctypes.c_int32
+        lib.xhe_batch_read_ledger.restype = ctypes.c_int32
+        ctx = ctypes.c_void_p(engine.ctx)
+        engine._check(lib.xhe_batch_upload(ctx, blob, offsets, ctypes.c_uint64(len(txs)), ctypes.byref(f["view"]), ctypes.byref(handle), ctypes.byref(v)))
+        try:
+            if v.accept:
+                engine._check(lib.xhe_batch_apply(ctx, handle, ctypes.byref(v)))
+            if not v.accept:
+                raise VerificationError(v.err_code, v.first_bad_tx)
+            out_cts = (ctypes.c_uint8 * max(64 * len(f["slots"]), 1))()
+            out_nonces = (ctypes.c_uint64 * max(len(f["keys"]), 1))()
+            ms_set = (ctypes.c_int64 * max(len(f["keys"]), 1))()
+            out = LedgerOut(out_cts, out_nonces, ms_set)
+            engine._check(lib.xhe_batch_read_ledger(ctx, handle, ctypes.byref(out)))
+        finally:
+            lib.xhe_batch_free(ctx, handle)
+        ledger.absorb(f, bytes(out_cts), list(out_nonces), list(ms_set), txs)
+
     def verify(self, engine, ledger: Ledger, seed=None):
         """Transaction::verify (verify.rs:520-542): a batch of one."""
         Transaction.verify_batch(engine, [self], ledger, seed)

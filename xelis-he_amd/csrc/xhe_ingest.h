@@ -46,6 +46,7 @@ struct host_batch {
     std::vector<dev_op> ops;               // sorted by slot
     std::vector<dev_sig> sigs;
     std::vector<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
+    std::vector<u32> apply_err;            // the subset apply_without_verify knows: unknown account / asset only
     std::vector<u32> rp_dec_tx;            // per decode entry: tx whose range proof owns the point, 0xffffffff otherwise
     std::vector<u32> slot_of_used;         // used slot -> ledger balance index
     std::vector<u32> slot_last_op;         // used slot -> index of its last op in ops[]
@@ -147,7 +148,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         return u;
     };
 
-    hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE);
+    hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE); hb.apply_err.assign(n, ERRKEY_NONE);
     {
         // sizes are known from the parsed records up to the ledger's first-touch points: reserve once
         u64 n_xf = 0, n_cm = 0, n_pts = 0, n_ms = 0;
@@ -163,6 +164,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     hb.lg_groups.assign(16, {});
     u32 term = 0, chal = 0;
     auto raise = [&](u64 i, u32 key) { if (key < hb.tx_err[i]) hb.tx_err[i] = key; };
+    auto raise_state = [&](u64 i, u32 key) { raise(i, key); if (key < hb.apply_err[i]) hb.apply_err[i] = key; };
 
     // pass 1: sigma-proof terms first so that they are contiguous (the sigma-only multiscalar check uses them)
     std::vector<u32> cm_term(n), xf_term(n);
@@ -203,7 +205,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         auto acc_it = account_of.find(make_key32(t.source()));
         bool src_known = acc_it != account_of.end();
         u32 src_acc = src_known ? acc_it->second : 0;
-        if (!src_known) raise(i, errkey(ST_NONCE, 0, 0, XHE_ERR_STATE));
+        if (!src_known) raise_state(i, errkey(ST_NONCE, 0, 0, XHE_ERR_STATE));
         else if (lv.account_nonces[src_acc] != t.nonce) raise(i, errkey(ST_NONCE, 0, 1, XHE_ERR_INVALID_NONCE));
         d.src_pt = src_known ? get_account_pt(src_acc) : new_point(rec + t.pre_off + 1, 0xffffffffu, 2);
         if (!record_commitment_assets_ok(t)) raise(i, errkey(ST_ASSETS, 0, 0, XHE_ERR_FORMAT));
@@ -254,7 +256,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             const u8 *asset = t.commitment(k);
             auto sl = src_known ? slot_of.find(slot_key(asset, src_acc)) : slot_of.end();
             u32 cm_index = (u32)hb.cms.size();
-            if (sl == slot_of.end()) raise(i, errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
+            if (sl == slot_of.end()) raise_state(i, errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
             else {
                 bool fresh; u32 u = touch_slot(sl->second, &fresh);
                 c.slot_pt = slot_pt[u]; c.first_touch = fresh ? 1 : 0;
@@ -284,11 +286,11 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             if (da == account_of.end()) {
                 x.dest_pt = new_point(x.off + 32, 0xffffffffu);
                 x.state_err = 1;
-                raise(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE));
+                raise_state(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE));
             } else {
                 x.dest_pt = get_account_pt(da->second);
                 auto sl = slot_of.find(slot_key(asset, da->second));
-                if (sl == slot_of.end()) { x.state_err = 1; raise(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE)); }
+                if (sl == slot_of.end()) { x.state_err = 1; raise_state(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE)); }
                 else {
                     bool fresh; u32 u = touch_slot(sl->second, &fresh);
                     x.slot_pt = slot_pt[u]; x.first_touch = fresh ? 1 : 0;

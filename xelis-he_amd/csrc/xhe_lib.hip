@@ -121,13 +121,13 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
+    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed})
             b->release();
@@ -372,7 +372,7 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
 #define UP(buf, vec) do { hipError_t e_ = upload_vec(B->buf, vec, st); if (e_ != hipSuccess) { set_error(ctx, std::string("upload " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
     UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
-    UP(tx_err0, hb.tx_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
+    UP(tx_err0, hb.tx_err); UP(apply_err0, hb.apply_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
     lap("uploads enqueued");
     u64 n_slots = hb.slot_of_used.size();
@@ -412,9 +412,60 @@ int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const
     return batch_verify_impl(ctx, B, verdict, rng_seed);
 }
 
+// Transaction::apply_without_verify for every transaction of the batch in order: the ledger arithmetic alone
+// (decode of the ledger and transfer ciphertexts, the ledger scan, the resulting encodings) on the main stream.
+int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
+    if (!ctx || !B || !verdict) return XHE_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const host_batch &hb = B->hb;
+    hipStream_t st = ctx->stream;
+    B->verified_ok = false;
+    if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
+    const u32 n_txs = (u32)hb.n_txs, n_cm = (u32)hb.cms.size(), n_ops = (u32)hb.ops.size(), n_slots = (u32)hb.slot_of_used.size();
+    stage_timer &tm = ctx->timer;
+    tm.begin();
+    HIPCHK(ctx, tm.mark("setup", st));
+    setup_jobs jobs;
+    memset(jobs.seed, 0, 32); jobs.seed_dst = nullptr;
+    jobs.fill(B->ok.p, 0x01010101u, (hb.n_points + 3) / 4);
+    jobs.copy(B->tx_err.p, B->apply_err0.p, std::max<u32>(n_txs, 1));
+    jobs.fill(B->rp_err.p, 0, std::max<u32>(n_txs, 1));
+    jobs.fill(B->emit_incl.p, 0, 64ull * (n_cm + 1));
+    jobs.fill(B->slot_base.p, 0, 64ull * (n_slots + 1));
+    jobs.fill(B->slot_final.p, 0, 64ull * (n_slots + 1));
+    jobs.fill(B->pts.as<u32>() + 32ull * hb.emit_base, 0, 32ull * hb.n_emit);
+    jobs.fill(B->verdict.p, 0xffffffffu, 4);
+    jobs.fill(B->verdict.as<u32>() + 4, 0, 12);
+    launch_setup(st, jobs);
+    if (n_txs) {
+        u32 *pts = B->pts.as<u32>(); u8 *ok = B->ok.as<u8>();
+        HIPCHK(ctx, tm.mark("decode_first", st));
+        launch_decode_list(st, B->bytes.as<u8>(), B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
+        HIPCHK(ctx, tm.mark("ledger_scan", st));
+        launch_ledger_scan(st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
+                           B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
+        if (n_ops) launch_ledger_final(st, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+        HIPCHK(ctx, tm.mark("verdict", st));
+        // only the ciphertexts were decoded: every other point still carries its initial "valid" mark
+        launch_point_errors(st, B->txs.as<dev_tx>(), B->cms.as<dev_cm>(), B->xfers.as<dev_xfer>(), n_txs, ok, B->tx_err.as<u32>(), B->rp_err.as<u32>());
+        launch_verdict(st, B->tx_err.as<u32>(), B->rp_err.as<u32>(), n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
+    }
+    HIPCHK(ctx, tm.mark("end", st));
+    HIPCHK(ctx, hipGetLastError());
+    u32 host[16];
+    HIPCHK(ctx, hipMemcpyAsync(host, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    tm.finish();
+    u64 first_err = (u64)host[0] | ((u64)host[1] << 32);
+    if (first_err != ~0ull) { *verdict = {0, (int32_t)(first_err & 0xff), (int64_t)(first_err >> 32)}; return 0; }
+    *verdict = {1, XHE_OK, -1};
+    B->verified_ok = true;
+    return 0;
+}
+
 int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *B, const xhe_ledger_out *out) {
     if (!ctx || !B || !out) return XHE_E_ARG;
-    if (!B->verified_ok) { set_error(ctx, "the batch has not been verified and accepted"); return XHE_E_ARG; }
+    if (!B->verified_ok) { set_error(ctx, "the batch has not been verified (or applied) and accepted"); return XHE_E_ARG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const host_batch &hb = B->hb;
     u64 n_slots = hb.slot_of_used.size();
