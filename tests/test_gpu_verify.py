@@ -389,3 +389,18 @@ def test_apply_without_verify_batch(engine, oracle):
         lib.xhe_batch_free(ctx, h)
         res.append(bytes(cts))
     assert res[0] == res[1]
+
+
+def test_transcript_stream_in_several_passes(engine, oracle, monkeypatch):
+    """The transcripts' byte stream is capped per pass (1 GiB); with the cap lowered to two tiles the 300 transactions
+    of this batch take three passes over the same buffer and must give the same challenges (verdict and ledger)."""
+    sb = SyntheticBatch(300, n_transfers=1, n_senders=20, seed=b"passes-300")
+    ref, ref_cts, _ = _raw_verify(None, oracle, None, sb)
+    monkeypatch.setenv("XHE_TRANSCRIPT_CAP_WORDS", str(2 * 21 * 64 * 30))
+    got, cts, _ = _raw_verify(engine.lib, engine, engine.ctx, sb)
+    assert got == ref == (1, codes.OK, -1) and cts == ref_cts
+    bad = bytearray(sb.records)
+    bad[list(sb.offsets)[280] + 16 + 4 + 49 + 100] ^= 1           # inside a transfer ciphertext of transaction 280 (last pass)
+    g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
+    r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
+    assert g == r and g[0] == 0 and g[2] == 280

@@ -328,12 +328,13 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         }
         transcript_pass cur{0, 0, 0};
         u64 cur_words = 0;
+        const u64 cap_words = transcript_stream_cap_words();
         for (u32 to : order) {
             const std::vector<u32> &v = by_tmpl[to];
             const u32 n_blocks = hb.tmpl[to + TT_H_BLOCKS];
             const u64 tile_words = 21ull * 64 * n_blocks;
             for (size_t k = 0; k < v.size(); k += 64) {
-                if (cur.n_tiles && cur_words + tile_words > TRANSCRIPT_STREAM_CAP_WORDS) {
+                if (cur.n_tiles && cur_words + tile_words > cap_words) {
                     hb.tr_plan.passes.push_back(cur);
                     cur = {(u32)hb.tr_tiles.size(), 0, 0}; cur_words = 0;
                 }
