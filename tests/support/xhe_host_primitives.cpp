@@ -76,8 +76,8 @@ u64 xt_merlin_script(const char *proto_label, const u8 *ops, u64 ops_len, u8 *ou
     }
     return w;
 }
-// Replays the transcript template of a record on the CPU: gathers every block's 168 bytes through the
-// descriptors, XORs them into a Keccak state, permutes, and squeezes the challenges where the template says.
+// Replays the transcript template of a record on the CPU: gathers every block's 21 state words through the
+// word descriptors, XORs them into a Keccak state, permutes, and squeezes the challenges where the template says.
 // Returns the number of challenges written (32 bytes each), -1 malformed record, -2 unsupported shape.
 // n_blocks_out / n_checks_failed_out (nullable) report the block count and the all-zero encodings found.
 long long xt_transcript_template_challenges(const u8 *rec, u64 len, u8 *out32, u64 cap, u32 *n_blocks_out, u32 *zero_checks_out) {
@@ -100,13 +100,13 @@ long long xt_transcript_template_challenges(const u8 *rec, u64 len, u8 *out32, u
         if (!acc) zeros++;
     }
     if (zero_checks_out) *zero_checks_out = zeros;
+    // the word gather reads up to 7 bytes before and after the fields it wants: give the record the slack the device buffer has
+    std::vector<u8> padded(len + 16, 0);
+    memcpy(padded.data() + 8, rec, len);
     keccak_state st; st.clear();
     long long n = 0;
     for (u32 b = 0; b < n_blocks; b++) {
-        for (u32 j = 0; j < TT_BLOCK_BYTES; j++) {
-            u32 d = desc[b * TT_BLOCK_BYTES + j];
-            st.bytes[j] ^= (d & TT_CONST) ? (u8)d : rec[seg[d >> 16] + (d & 0xffffu)];
-        }
+        for (u32 w = 0; w < TT_WORDS; w++) st.lanes[w] ^= transcript_word(desc + ((u64)b * TT_WORDS + w) * TT_WDESC, padded.data() + 8, seg.data());
         st.permute();
         if (chal_after[b] != TT_NONE) {
             if ((u64)chal_after[b] < cap) { sc x = sc_from_wide_bytes(st.bytes); sc_tobytes(out32 + 32 * chal_after[b], x); }

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) k_transcript_serial(const u8 *__restrict__
 // The transcript itself is data: per block of 168 bytes a list of byte descriptors
 // (xhe_transcript_template.h), so absorbing is a gather and no thread interprets STROBE.  Two kernels:
 //   k_transcript_stage   gathers every 8-byte state word of every block of every transaction (massively
-//                        parallel, byte loads from the unaligned records) into a stream laid out
+//                        parallel, at most two unaligned 8-byte loads from the record per word) into a stream laid out
 //                        [tile of 64 transactions][block][word][lane], and runs the all-zero-encoding checks;
 //   k_transcript_keccak  one thread per transaction with the 25 state words in registers: per block 21
 //                        coalesced 8-byte loads, XOR, Keccak-f[1600]; a challenge is squeezed where the
@@ -114,21 +114,12 @@ __global__ void __launch_bounds__(64) k_transcript_serial(const u8 *__restrict__
 static constexpr u32 TR_PAD = 0xffffffffu;
 static constexpr u32 STAGE_ROWS = 7;         // words of a block handled per pass of a 448-thread workgroup
 
-// the eight bytes of state word l (< 21) of block b, assembled from the descriptors
+// the eight bytes of state word l (< 21) of block b through its word descriptor (transcript_word)
 __device__ __forceinline__ u64 transcript_gather(const u32 *__restrict__ desc, u32 b, u32 l, const u8 *__restrict__ rec, const u32 *__restrict__ seg) {
-    const uint4 *dp = (const uint4 *)(desc + (u64)b * TT_BLOCK_BYTES + 8 * l);
+    const uint4 *dp = (const uint4 *)(desc + ((u64)b * TT_WORDS + l) * TT_WDESC);
     uint4 d0 = dp[0], d1 = dp[1];
-    u32 ds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-    u64 word = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        bool is_const = (ds[k] & TT_CONST) != 0;
-        u32 off = is_const ? 0u : seg[ds[k] >> 16] + (ds[k] & 0xffffu);
-        u32 byte = rec[off];
-        byte = is_const ? (ds[k] & 0xffu) : byte;
-        word |= (u64)byte << (8 * k);
-    }
-    return word;
+    u32 d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    return transcript_word(d, rec, seg);
 }
 
 __global__ void __launch_bounds__(64 * STAGE_ROWS) k_transcript_stage(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl,

@@ -5,10 +5,18 @@
 // source commitments / transfers / multisig signers, range-proof size): labels, lengths, STROBE operation
 // headers and padding are constants, everything else is a byte of the record at a fixed offset inside one
 // of the transaction's segments (pre-image, range proof, commitment k, transfer k, transfer proof k).  A
-// template lists, per block, 168 byte descriptors plus the index of the Fiat-Shamir challenge that is
-// squeezed after the block's permutation (if any), and the encodings that must not be all-zero
-// (validate_and_append_point, /root/reference/src/transcript.rs:70-85).  The device kernel then only
-// gathers bytes and permutes; it never interprets STROBE.
+// template lists, per block, the 21 eight-byte state words as word descriptors plus the index of the
+// Fiat-Shamir challenge that is squeezed after the block's permutation (if any), and the encodings that must
+// not be all-zero (validate_and_append_point, /root/reference/src/transcript.rs:70-85).  The device kernel
+// then only gathers and permutes; it never interprets STROBE.
+//
+// A word descriptor is eight 32-bit words: the constant bytes of the word (data positions zero) and up to two
+// "runs" of record bytes.  STROBE puts at least nine framing bytes between two data fields, so one state word
+// never holds bytes of more than two fields.  A run is fetched with one unaligned 8-byte load placed so that
+// the wanted source bytes fall on their positions in the word, then masked: {seg << 16 | (start + 8), control}
+// with start = source offset of the load relative to the segment (may be down to -7) and control =
+// first byte | length << 4 | reversed << 8 | valid << 9 (reversed: the big-endian integers of the record are
+// absorbed little-endian, so the eight loaded bytes are swapped end for end first).
 //
 // Mirrors strobe128 / transcript of xhe_hash.h operation by operation (same begin_op / run_f rules), and
 // the append order of k_transcript_serial (/root/reference/src/tx/verify.rs:146-158,315-326,378-399,420-424
@@ -30,7 +38,27 @@ static constexpr u32 TT_MAX_SEGS = 32768, TT_MAX_OFF = 65536;
 // header words of a template inside the device array
 enum : u32 { TT_H_BLOCKS = 0, TT_H_CHALS = 1, TT_H_CHECKS = 2, TT_H_DESC = 3, TT_H_WORDS = 4 };
 // layout: header[4] | chal_after[n_blocks] | checks[n_checks][2] (descriptor of the first byte, error key; key 0 = range-proof flag) |
-// padding | desc[n_blocks][168], the descriptors starting at word header[TT_H_DESC] of the array, a multiple of 8
+// padding | wdesc[n_blocks][21][8], the word descriptors starting at word header[TT_H_DESC] of the array, a multiple of 8
+static constexpr u32 TT_WORDS = 21, TT_WDESC = 8;      // state words per block, 32-bit words per word descriptor
+static constexpr u32 TT_RUN_VALID = 1u << 9, TT_RUN_REVERSED = 1u << 8;
+
+// the eight bytes of a state word from its descriptor (host replay and device gather share this)
+XHE_HD u64 transcript_word(const u32 d[8], const u8 *rec, const u32 *seg) {
+    u64 word = (u64)d[0] | ((u64)d[1] << 32);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const u32 src = d[2 + 2 * r], ctl = d[3 + 2 * r];
+        if (!(ctl & TT_RUN_VALID)) continue;
+        const u8 *p = rec + seg[src >> 16] + (src & 0xffffu) - 8;
+        u64 v;
+        __builtin_memcpy(&v, p, 8);
+        if (ctl & TT_RUN_REVERSED) v = __builtin_bswap64(v);
+        const u32 first = ctl & 15, len = (ctl >> 4) & 15;
+        const u64 mask = (len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1)) << (8 * first);
+        word |= v & mask;
+    }
+    return word;
+}
 
 struct transcript_shape {
     u8 type; u32 n_commitments, n_transfers, n_items, m, lg;
@@ -53,11 +81,12 @@ static inline bool transcript_shape_supported(const transcript_shape &s) {
 
 struct strobe_recorder {
     static constexpr u32 R = 166;
-    std::vector<u32> desc, chal_after;
-    u32 cur[TT_BLOCK_BYTES];
+    std::vector<u32> desc, chal_after;          // desc: one entry per stream byte (constant, or seg << 16 | offset)
+    std::vector<u8> rev;                         // per stream byte: 1 when it belongs to a field absorbed end for end
+    u32 cur[TT_BLOCK_BYTES]; u8 cur_rev[TT_BLOCK_BYTES];
     u32 pos = 0, pos_begin = 0, n_chal = 0;
-    void clear_cur() { for (u32 j = 0; j < TT_BLOCK_BYTES; j++) cur[j] = TT_CONST; }
-    void emit() { desc.insert(desc.end(), cur, cur + TT_BLOCK_BYTES); chal_after.push_back(TT_NONE); clear_cur(); }
+    void clear_cur() { for (u32 j = 0; j < TT_BLOCK_BYTES; j++) { cur[j] = TT_CONST; cur_rev[j] = 0; } }
+    void emit() { desc.insert(desc.end(), cur, cur + TT_BLOCK_BYTES); rev.insert(rev.end(), cur_rev, cur_rev + TT_BLOCK_BYTES); chal_after.push_back(TT_NONE); clear_cur(); }
     void xor_const(u32 j, u8 v) { assert(cur[j] & TT_CONST); cur[j] ^= v; }
     void run_f() { xor_const(pos, (u8)pos_begin); xor_const(pos + 1, 0x04); xor_const(R + 1, 0x80); emit(); pos = 0; pos_begin = 0; }
     void absorb_const(const u8 *d, u32 n) { for (u32 i = 0; i < n; i++) { xor_const(pos++, d[i]); if (pos == R) run_f(); } }
@@ -65,6 +94,7 @@ struct strobe_recorder {
         for (u32 i = 0; i < n; i++) {
             u32 o = reversed ? off + n - 1 - i : off + i;
             assert(seg < TT_MAX_SEGS && o < TT_MAX_OFF && cur[pos] == TT_CONST);
+            cur_rev[pos] = reversed ? 1 : 0;
             cur[pos++] = (seg << 16) | o;
             if (pos == R) run_f();
         }
@@ -180,7 +210,31 @@ static inline u32 build_transcript_template(std::vector<u32> &out, const transcr
     out.insert(out.end(), checks.begin(), checks.end());
     while (out.size() % 8) out.push_back(0);
     out[base + TT_H_DESC] = (u32)out.size();
-    out.insert(out.end(), r.desc.begin(), r.desc.end());
+    for (u32 b = 0; b < n_blocks; b++)
+        for (u32 w = 0; w < TT_WORDS; w++) {
+            const u32 *bd = r.desc.data() + (u64)b * TT_BLOCK_BYTES + 8 * w;
+            const u8 *br = r.rev.data() + (u64)b * TT_BLOCK_BYTES + 8 * w;
+            u32 d[TT_WDESC] = {0, 0, 0, 0, 0, 0, 0, 0};
+            u32 n_runs = 0;
+            for (u32 j = 0; j < 8;) {
+                if (bd[j] & TT_CONST) { u64 c = (u64)(bd[j] & 0xffu) << (8 * j); d[0] |= (u32)c; d[1] |= (u32)(c >> 32); j++; continue; }
+                // maximal run of bytes of one segment whose offsets step by +1 (or -1 for a reversed field)
+                const u32 seg = bd[j] >> 16, off = bd[j] & 0xffffu; const bool reversed = br[j] != 0;
+                u32 len = 1;
+                while (j + len < 8 && !(bd[j + len] & TT_CONST) && (bd[j + len] >> 16) == seg && (br[j + len] != 0) == reversed &&
+                       (bd[j + len] & 0xffffu) == (reversed ? off - len : off + len)) len++;
+                assert(n_runs < 2 && "a state word holds bytes of at most two fields");
+                // forward: byte j of the word is source byte off, so the load starts at off - j; reversed: after the
+                // end-for-end swap byte j is source byte start + 7 - j, so start = off + j - 7
+                const int start = reversed ? (int)off + (int)j - 7 : (int)off - (int)j;
+                assert(start + 8 >= 0 && start + 8 < (int)TT_MAX_OFF);
+                d[2 + 2 * n_runs] = (seg << 16) | (u32)(start + 8);
+                d[3 + 2 * n_runs] = j | (len << 4) | (reversed ? TT_RUN_REVERSED : 0) | TT_RUN_VALID;
+                n_runs++;
+                j += len;
+            }
+            out.insert(out.end(), d, d + TT_WDESC);
+        }
     while (out.size() % 8) out.push_back(0);
     return base;
 }
