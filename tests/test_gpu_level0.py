@@ -53,7 +53,7 @@ def test_decompress_compress_parity(engine, oracle):
     assert engine.decompress_batch(b"") == (b"", b"")
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 64, 189, 190, 255, 256, 499, 800, 4096, 5000, 40000])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 64, 189, 190, 255, 256, 499, 800, 4096, 5000, 40000, 199999, 200000, 262144])
 def test_msm_parity(engine, oracle, n):
     r = rng(1000 + n)
     pool = _oracle_points(oracle, r, min(max(n, 1), 64))
@@ -67,9 +67,10 @@ def test_msm_parity(engine, oracle, n):
     assert ident == bool(idf[0])
 
 
-@pytest.mark.parametrize("n,kind", [(3000, "equal"), (3000, "two"), (20000, "small"), (70000, "equal")])
+@pytest.mark.parametrize("n,kind", [(3000, "equal"), (3000, "two"), (20000, "small"), (70000, "equal"), (210000, "equal"), (210000, "two"), (210000, "small")])
 def test_msm_skewed_digits(engine, oracle, n, kind):
-    """Digit distributions that put most terms into a handful of buckets (buckets spanning many chunks)."""
+    """Digit distributions that put most terms into a handful of buckets (buckets spanning many chunks; from 200 000
+    terms on the sort runs in two passes and all of a window's terms meet in one coarse bin)."""
     r = rng(5000 + n)
     pool = _oracle_points(oracle, r, 32)
     pts = b"".join(pool[r.randrange(32)] for _ in range(n))

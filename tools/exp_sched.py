@@ -16,6 +16,10 @@ eng._check(lib.xhe_batch_upload(ctypes.c_void_p(eng.ctx), batch.records, batch.o
 v = Verdict()
 for e in exps:
     os.environ["XHE_EXP"] = str(e)
+    if e & 1:
+        os.environ["XHE_MSM_ONEPASS"] = "1"
+    else:
+        os.environ.pop("XHE_MSM_ONEPASS", None)
     acc = {}
     reps = 6
     t0 = None

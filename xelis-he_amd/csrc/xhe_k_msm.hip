@@ -4,11 +4,12 @@
 //
 // Pipeline (every stage one launch over the whole problem):
 //   digits            thread per term: signed radix-2^c digits, stored window-major as 16-bit sign|magnitude
-//   tile histogram    workgroup per (window, tile of 8192 terms): bucket counts in LDS, no global atomics
+//   tile histogram    workgroup per (window, tile of 8192..32768 terms): bucket counts in LDS, no global atomics
 //   tile prefix       thread per (window, bucket): running sum over the tiles, totals per bucket
 //   scan              exclusive prefix sum of the W*B totals
 //   scatter           workgroup per (window, tile): positions from LDS counters seeded with
 //                     offset[bucket] + prefix[tile][bucket]; term index (+sign bit) into its bucket's segment
+//                     (from 200 000 terms on: the same three steps over coarse bins, then a sort inside every bin)
 //   accumulate        thread per chunk of M consecutive entries of the bucket-sorted array: mixed additions of
 //                     the entries' affine-Niels points; buckets that lie inside the chunk are finished there,
 //                     the (at most two) buckets cut by the chunk's borders leave partial sums
@@ -21,6 +22,7 @@
 //   horner            the 252 doublings over the window sums on one quad of lanes, compress, identity test
 // Points come in as 128-byte affine-Niels records (xhe_ge.h), scalars as canonical 32-byte values.
 // The work per thread of the accumulate stage is M additions whatever the distribution of the digits.
+#include <stdlib.h>
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_quad.h"
@@ -49,23 +51,30 @@ msm_plan msm_make_plan(u64 n) {
     if (M < 16 && entries >= (1u << 16)) M = 16;
     if (M < 32 && entries >= (1u << 20)) M = 32;
     p.M = M;
+    // terms per workgroup of the counting sort: every workgroup reads and writes all B counters of its window, so a tile
+    // holds at least two terms per bucket once there are enough tiles (tiles * W workgroups) to cover the chip
+    p.tile = 8192;
+    while (p.tile < 2 * p.B && n / (2ull * p.tile) * p.W >= 1024) p.tile *= 2;
+    // Large sorts go in two passes (term index in 24 bits + 7 bits of the bucket + sign in one word): scattering straight into
+    // 2^13..2^14 buckets per window writes every 4-byte entry to a line of its own, which is what bounds the one-pass form.
+    p.fine_bits = (c >= 14 && n <= (1u << 24) && !getenv("XHE_MSM_ONEPASS")) ? 7 : 0;
     return p;
 }
 
 static constexpr u32 SCAN_TILE = 1024;       // counters per workgroup of the bucket-offset scan
 static constexpr u32 MERGE_SPAN_MAX = 8;     // a bucket cut into more chunks than this is reduced by a workgroup
 
-static constexpr u32 SORT_TILE = 8192;        // terms per workgroup of the counting sort
-static inline u64 msm_sort_tiles(u64 n) { return n ? (n + SORT_TILE - 1) / SORT_TILE : 1; }
+static inline u64 msm_sort_tiles(u64 n, const msm_plan &p) { return n ? (n + p.tile - 1) / p.tile : 1; }
 static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return (e + p.M - 1) / p.M + 1; }
 
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
     u64 nb = (u64)p.W * p.B, entries = n * p.W, chunks = msm_chunks(n, p);
     msm_ws_bytes b;
-    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.tile_hist = nb * msm_sort_tiles(n) * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
+    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.tile_hist = nb * msm_sort_tiles(n, p) * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
     b.digits = (entries ? entries : 1) * 2;
     b.chunk_sums = chunks * 2 * 128; b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
     b.segs = (u64)p.W * p.S * 2 * 128 + (nb / SCAN_TILE + 1) * 4; b.wins = (u64)p.W * 128;          // segs doubles as the scan's tile sums
+    b.tmp = p.fine_bits ? b.sorted : 64; b.coarse = ((u64)p.W * (p.B >> p.fine_bits) + 1) * 4 + 64;
     return b;
 }
 
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__r
     const u32 tile = blockIdx.x, w = blockIdx.y;
     for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    u64 lo = (u64)tile * SORT_TILE, hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
     for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         u32 a = digits[(u64)w * n + k] & 0x7fffu;
         if (a) atomicAdd(&cnt[a - 1], 1u);
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__res
     const u32 *off = offsets + (u64)w * p.B;
     for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = off[b] + pre[b];
     __syncthreads();
-    u64 lo = (u64)tile * SORT_TILE, hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
     for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         u32 d = digits[(u64)w * n + k];
         u32 a = d & 0x7fffu;
@@ -224,6 +233,79 @@ __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__res
         }
     }
 }
+// ---- two-pass sort ---------------------------------------------------------------------------------------
+// Pass 1 distributes the entries of a window over B >> f coarse bins (the high bits of the bucket index), pass 2 sorts
+// each bin by the low f bits.  A pass-1 workgroup appends to few, long segments (its writes combine in L2); a pass-2
+// workgroup owns one bin (tens of thousands of entries, read twice in order) and writes inside that bin's range only.
+// Entry format between the passes: term index [23:0], low bucket bits [30:24], sign [31].
+__global__ void __launch_bounds__(512) k_msm_coarse_hist(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, u32 *__restrict__ tile_hist) {
+    wave_priority_high();
+    extern __shared__ u32 cnt[];
+    const u32 tile = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
+    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 a = digits[(u64)w * n + k] & 0x7fffu;
+        if (a) atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
+    }
+    __syncthreads();
+    u32 *out = tile_hist + ((u64)w * tiles + tile) * nb;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = cnt[b];
+}
+__global__ void __launch_bounds__(512) k_msm_coarse_scatter(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
+                                                            const u32 *__restrict__ coarse_off, u32 *__restrict__ tmp, u64 cap) {
+    wave_priority_high();
+    extern __shared__ u32 cnt[];
+    const u32 tile = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits, fine_mask = (1u << p.fine_bits) - 1;
+    const u32 *pre = tile_hist + ((u64)w * tiles + tile) * nb;
+    const u32 *off = coarse_off + (u64)w * nb;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = off[b] + pre[b];
+    __syncthreads();
+    u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
+    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        u32 d = digits[(u64)w * n + k];
+        u32 a = d & 0x7fffu;
+        if (a) {
+            u32 pos = atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
+            if (pos < cap) tmp[pos] = (u32)k | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
+        }
+    }
+}
+// workgroup per (coarse bin, window): bucket offsets of the bin's 2^f buckets and the entries in bucket order
+__global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ tmp, const u32 *__restrict__ coarse_off, msm_plan p, u32 *__restrict__ offsets,
+                                                       u32 *__restrict__ sorted, u64 cap) {
+    wave_priority_high();
+    __shared__ u32 cnt[128], scan[128];
+    const u32 bin = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits, F = 1u << p.fine_bits, t = threadIdx.x;
+    const u32 s = coarse_off[(u64)w * nb + bin], e = coarse_off[(u64)w * nb + bin + 1];
+    if (t < F) cnt[t] = 0;
+    __syncthreads();
+    for (u32 k = s + t; k < e; k += blockDim.x) atomicAdd(&cnt[(tmp[k] >> 24) & 127u], 1u);
+    __syncthreads();
+    u32 own = t < F ? cnt[t] : 0;
+    if (t < F) scan[t] = own;
+    __syncthreads();
+    for (u32 d = 1; d < F; d <<= 1) {                 // inclusive scan of at most 128 counters
+        u32 o = (t < F && t >= d) ? scan[t - d] : 0;
+        __syncthreads();
+        if (t < F) scan[t] += o;
+        __syncthreads();
+    }
+    if (t < F) {
+        u32 excl = scan[t] - own;
+        offsets[(u64)w * p.B + (u64)bin * F + t] = s + excl;
+        cnt[t] = s + excl;
+    }
+    if (t == 0 && bin == nb - 1 && w == p.W - 1) offsets[(u64)p.W * p.B] = e;
+    __syncthreads();
+    for (u32 k = s + t; k < e; k += blockDim.x) {
+        u32 v = tmp[k];
+        u32 pos = atomicAdd(&cnt[(v >> 24) & 127u], 1u);
+        if (pos < cap) sorted[pos] = v & 0x80ffffffu;
+    }
+}
+
 __device__ __forceinline__ ge ge_shfl_down(const ge &p, u32 delta) {
     ge r;
 #pragma unroll
@@ -508,18 +590,32 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
     hipError_t e;
-    const u32 tiles = (u32)msm_sort_tiles(n), lds_bytes = p.B * 4;
+    const u32 tiles = (u32)msm_sort_tiles(n, p), lds_bytes = p.B * 4;
     unsigned short *digits = (unsigned short *)ws.digits;
     MARK("msm_histogram");
     hipLaunchKernelGGL(k_msm_digits, dim3(n ? grid_for(n, 256) : 1), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list);
-    hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
-    hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);
-    MARK("msm_scan");
-    u32 scan_tiles = (u32)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
-    hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets);
-    MARK("msm_scatter");
-    hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap);
+    if (!p.fine_bits) {
+        hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
+        hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);
+        MARK("msm_scan");
+        u32 scan_tiles = (u32)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
+        hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets);
+        MARK("msm_scatter");
+        hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap);
+    } else {
+        msm_plan q = p; q.B = p.B >> p.fine_bits;      // the coarse bins play the buckets' part in the prefix and scan kernels
+        const u32 n_bins = p.W * q.B;
+        hipLaunchKernelGGL(k_msm_coarse_hist, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist);
+        hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_bins, 256)), dim3(256), 0, st, ws.tile_hist, q, tiles, ws.hist);
+        MARK("msm_scan");
+        u32 scan_tiles = (n_bins + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, n_bins, ws.segs);
+        hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, n_bins, ws.segs, ws.coarse);
+        MARK("msm_scatter");
+        hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap);
+        hipLaunchKernelGGL(k_msm_fine_sort, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);
+    }
     MARK("msm_wait_points");
     for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
     MARK("msm_accumulate");

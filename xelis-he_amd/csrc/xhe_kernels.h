@@ -13,13 +13,15 @@ struct msm_plan {
     u32 L;        // buckets per lane in the reduce stage
     u32 S;        // segments per window = B / (64 L)   (<= 64)
     u32 M;        // sorted entries per accumulate chunk
+    u32 tile;     // terms per workgroup of the counting sort
+    u32 fine_bits;  // 0: one-pass counting sort over all B buckets; f > 0: two passes, B >> f coarse bins, then 2^f buckets inside each bin
 };
 msm_plan msm_make_plan(u64 n);
 // device pointers of one multiscalar multiplication's workspace (sizes: see msm_workspace_bytes)
 struct msm_ws {
-    u32 *hist, *offsets, *tile_hist, *sorted, *buckets, *digits, *chunk_sums, *big_list, *segs, *wins;
+    u32 *hist, *offsets, *tile_hist, *sorted, *buckets, *digits, *chunk_sums, *big_list, *segs, *wins, *tmp, *coarse;
 };
-struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins; };
+struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
 // result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)

@@ -93,7 +93,7 @@ struct stage_timer {
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
 };
 
-struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins; };
+struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
 
 struct xhe_ctx {
     int device = 0;
@@ -156,8 +156,10 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.big_list.reserve(need.big_list));
     HIPCHK(ctx, ws.segs.reserve(need.segs));
     HIPCHK(ctx, ws.wins.reserve(need.wins));
+    HIPCHK(ctx, ws.tmp.reserve(need.tmp));
+    HIPCHK(ctx, ws.coarse.reserve(need.coarse));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.tile_hist.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), ws.digits.as<u32>(), ws.chunk_sums.as<u32>(),
-             ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>()};
+             ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>(), ws.tmp.as<u32>(), ws.coarse.as<u32>()};
     HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, timing ? timer_mark : nullptr, ctx));
     return 0;
 }
@@ -242,7 +244,7 @@ void xhe_destroy(xhe_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
-                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
+                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
     for (hipEvent_t e : {ctx->ev_sig_absorbed, ctx->ev_static_done, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
