@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Schedule experiments: one synthetic batch, verified under several XHE_EXP settings; prints stage times.
-usage: tools/exp_sched.py <txs> <transfers> <exp values...>"""
+"""Stage times of one synthetic batch (generated once, verified several times), optionally under variants of the library
+selected through the environment: variant bit 0 = one-pass multiscalar sort (XHE_MSM_ONEPASS).
+usage: tools/exp_sched.py <txs> <transfers> <variant values...>"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +16,6 @@ h = ctypes.c_void_p(); sv = Verdict()
 eng._check(lib.xhe_batch_upload(ctypes.c_void_p(eng.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view, ctypes.byref(h), ctypes.byref(sv)))
 v = Verdict()
 for e in exps:
-    os.environ["XHE_EXP"] = str(e)
     if e & 1:
         os.environ["XHE_MSM_ONEPASS"] = "1"
     else:
