@@ -112,7 +112,7 @@ def main():
 
     verdict = Verdict()
     on_host = args.backend != "nccl"              # gloo gets host tensors only
-    flag = torch.ones(1, dtype=torch.int64, device="cpu" if on_host else "cuda")
+    flag = torch.ones(1, dtype=torch.int64, device="cpu" if (on_host or dist is None) else "cuda")
 
     def step(i):
         seed = (i + 1).to_bytes(8, "little") * 4

@@ -4,7 +4,7 @@
  * are the Rust calls named beside each entry point.  Every entry point takes plain pointers and sizes;
  * all multi-byte integers in buffers are little-endian unless stated; all buffers are caller-owned
  * host memory unless the name says "_dev".  Return value: 0 = the call ran (the verdict is in the out
- * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns four HIP streams
+ * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns three HIP streams
  * there, all at the default priority) and must not be used from two threads at once; different contexts
  * are independent.
  */

@@ -82,15 +82,15 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 
 // ---- decode ----------------------------------------------------------------------------------------
 static constexpr u32 DECODE_MAX_BLOCKS = 512;
-// list != null: the first pass over the n listed entries (the points the ledger scan and the signatures
-// wait for); list == null: all n entries except those of the first pass
+// list != null: the first pass over the n listed entries (the points the ledger scan waits for);
+// list == null: all n entries except those of the first pass (early == 1)
 __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok) {
     if (list) wave_priority_high(); else wave_priority_mid();      // listed points head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         u32 i = g;
         if (list) i = list[g];
-        else if (decs[g].early) continue;
+        else if (decs[g].early == 1) continue;
         u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);
         ge p; bool good = ristretto_decode_words(p, w);
         ge_niels_store(pts + 32ull * (pt_base + i), ge_to_niels_affine(p));

@@ -1,9 +1,10 @@
 // Schnorr signature verification (/root/reference/src/elgamal.rs:38-65): accept iff
-// e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Three kernels, the first two independent of each other:
-//   k_sig_absorb   thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
+// e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Three parts, the first two independent of each other and run as the
+// two kinds of workgroups of one launch (k_sig_point_absorb):
+//   absorb         thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
 //                  held in registers (the bulk of the hashing: 19 of the 20 permutations for a one-transfer
 //                  transaction) -- needs no point, so it runs beside the point kernel;
-//   k_sig_point    four lanes per signature (xhe_quad.h): s*H from the 8-bit fixed-base table, e*P with signed
+//   point          four lanes per signature (xhe_quad.h): s*H from the 8-bit fixed-base table, e*P with signed
 //                  4-bit windows over a table of 0..8 P kept in LDS, R = s*H - e*P as an XYZT record;
 //   k_sig_final    thread per signature: encodes R, absorbs the message tail || enc(R) || padding, squeezes,
 //                  reduces mod l and compares with e.
@@ -34,8 +35,8 @@ __device__ __forceinline__ sig_stream sig_stream_of(const dev_sig &sg, const u8 
 __device__ __forceinline__ u32 sig_whole_blocks(const dev_sig &sg) { return sg.hash_idx != 0xffffffffu ? 0u : (32u + sg.msg_len) / 72u; }
 
 // state[w * n + i]: word w of signature i's sponge after its whole blocks
-__global__ void __launch_bounds__(64) k_sig_absorb(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, u64 *__restrict__ state) {
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void sig_absorb_work(u32 block, u32 n_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, u64 *__restrict__ state) {
+    for (u32 i = block * 64 + threadIdx.x; i < n; i += n_blocks * 64) {
     const dev_sig sg = sigs[i];
     const u32 nb = sig_whole_blocks(sg);
     const u8 *key = bytes + sg.key_off, *msg = bytes + sg.msg_off;
@@ -85,11 +86,10 @@ __device__ __forceinline__ qd_point qd_add_cached(const qd_point &p, const fe &c
 
 static constexpr u32 SIG_QUADS = 16;          // signatures per 64-thread workgroup
 
-__global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u32 *__restrict__ pts,
-                                                  const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
-    __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
+__device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, u32 (*tab)[10][64], const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+                                               const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
     const u32 lane = threadIdx.x, role = lane & 3;
-    for (u32 group = blockIdx.x; group * SIG_QUADS < n; group += gridDim.x) {
+    for (u32 group = block; group * SIG_QUADS < n; group += n_blocks) {
     const u32 q = group * SIG_QUADS + (lane >> 2);
     const u32 i = q < n ? q : n - 1;           // spare quads repeat the last signature and store nothing
     const dev_sig sg = sigs[i];
@@ -146,6 +146,15 @@ __global__ void __launch_bounds__(64) k_sig_point(const u8 *__restrict__ bytes, 
     }
 }
 
+// One launch for the two independent parts: workgroups [0, point_blocks) compute the points, the others absorb the
+// message blocks (both grid-stride over their share).
+__global__ void __launch_bounds__(64) k_sig_point_absorb(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+                                                         const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
+    __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
+    if (blockIdx.x < point_blocks) sig_point_work(blockIdx.x, point_blocks, tab, bytes, sigs, n, pts, htab, r_out);
+    else sig_absorb_work(blockIdx.x - point_blocks, gridDim.x - point_blocks, bytes, sigs, n, state);
+}
+
 __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n, const u64 *__restrict__ state,
                                                   const u32 *__restrict__ r_in, const u8 *__restrict__ ok, const u8 *__restrict__ ms_hash, u32 *__restrict__ tx_err) {
     __shared__ u8 tail[2 * SIG_RATE_WORDS][64][8];       // [word][lane][byte]: the last one or two blocks of each signature
@@ -187,13 +196,12 @@ __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, 
     if (diff) raise_err(tx_err, sg.tx, sg.err_key);
 }
 
-void launch_sig_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, u64 *state) {
-    u32 blocks = grid_for(n, 64);
-    if (n) hipLaunchKernelGGL(k_sig_absorb, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, bytes, sigs, n, state);
-}
-void launch_sig_point(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u32 *htab, u32 *r_out) {
-    u32 blocks = grid_for(n, SIG_QUADS);
-    if (n) hipLaunchKernelGGL(k_sig_point, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, bytes, sigs, n, pts, htab, r_out);
+void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state) {
+    if (!n) return;
+    u32 pb = grid_for(n, SIG_QUADS), ab = grid_for(n, 64);
+    if (pb > SIG_MAX_WAVES) pb = SIG_MAX_WAVES;
+    if (ab > SIG_MAX_WAVES) ab = SIG_MAX_WAVES;
+    hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, pts, htab, r_out, state);
 }
 void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err) {
     if (n) hipLaunchKernelGGL(k_sig_final, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state, r_in, ok, ms_hash, tx_err);

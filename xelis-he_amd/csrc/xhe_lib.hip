@@ -98,9 +98,9 @@ struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits
 struct xhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};            // [0] ledger scan + static-generator scalars, [1] signatures, [2] bulk point decoding + signature
-                                                                  // hashing; with the main stream one per hardware queue, all at the default priority
-    hipEvent_t ev_sig_absorbed = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_decoded = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[2] = {nullptr, nullptr};                     // [0] ledger scan + static-generator scalars, [1] point decoding + signatures; with the main
+                                                                  // stream three of the process's four hardware queues, all at the default priority
+    hipEvent_t ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -231,9 +231,8 @@ xhe_ctx *xhe_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess &&
-              hipStreamCreate(&ctx->side[2]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_sig_absorbed, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_decoded, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -242,13 +241,13 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_sig_absorbed, ctx->ev_static_done, ctx->ev_setup, ctx->ev_decoded, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -540,13 +539,12 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *tx_err = B->tx_err.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
     const u32 *sd = B->seed.as<u32>();
 
-    // Four streams: the device exposes four hardware queues to a process, and streams that share a queue run one
-    // after the other.  Enqueue order = who gets wave slots first.
+    // Three streams: the device exposes four hardware queues to a process, streams that share a queue run one after the
+    // other, and the caller (its own stream, RCCL) needs one too.  Enqueue order = who gets wave slots first.
     //   main     transcripts -> proof scalars -> multiscalar check -> verdict
     //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
-    //   side 1   public keys -> signature points -> end of the signature hashes
-    //   side 2   every other point of the batch -> the signatures' hashing up to their last block
-    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1], s2 = ctx->side[2];
+    //   side 1   every other point of the batch (public keys included) -> signature points + hashing -> end of the signature hashes
+    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1];
     HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
@@ -560,27 +558,16 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
                        B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
     HIPCHK(ctx, tm.close("ledger_scan", s0));
-    // side 1: public keys, then the signatures' points
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // ledger inputs and the senders' new ciphertexts are in place
+    // side 1: the bulk of the points (public keys included), then the signatures
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
+    HIPCHK(ctx, tm.open("decode_rest", s1));
+    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
+    HIPCHK(ctx, tm.close("decode_rest", s1));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s1));             // every point that is not the ledger scan's
     HIPCHK(ctx, tm.open("signatures", s1));
-    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_decoded, s1));
     launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
-    launch_sig_point(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>());
-    HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_decoded, 0));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // keys, ledger inputs and the senders' new ciphertexts are in place
-    // side 2: every other point of the batch, then the signatures' hashing up to the last block (needs no point)
-    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->ev_setup, 0));
-    HIPCHK(ctx, tm.open("decode_rest", s2));
-    launch_decode_list(s2, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.close("decode_rest", s2));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s2));
-    HIPCHK(ctx, tm.open("signature_hash", s2));
-    launch_sig_absorb(s2, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>());
-    HIPCHK(ctx, tm.close("signature_hash", s2));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_sig_absorbed, s2));
-    // side 1 again: the end of the signature hashes
-    HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_sig_absorbed, 0));
+    launch_sig_point_absorb(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>(), B->sig_state.as<u64>());
     launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.close("signatures", s1));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
