@@ -93,14 +93,16 @@ struct stage_timer {
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
 };
 
+static constexpr u32 SIG_STREAM_MIN_TXS = 32768;     // from this batch size on the signatures get a stream of their own
+
 struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
 
 struct xhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
-    hipStream_t side[2] = {nullptr, nullptr};                     // [0] ledger scan + static-generator scalars, [1] point decoding + signatures; with the main
-                                                                  // stream three of the process's four hardware queues, all at the default priority
-    hipEvent_t ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};            // [0] ledger scan + static-generator scalars, [1] point decoding (+ signatures), [2] signatures of
+                                                                  // large batches only; all at the default priority
+    hipEvent_t ev_keys = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
     // level-0 workspace
@@ -231,8 +233,8 @@ xhe_ctx *xhe_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess && hipStreamCreate(&ctx->side[2]) == hipSuccess;
+    for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
@@ -241,13 +243,13 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -539,8 +541,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *tx_err = B->tx_err.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
     const u32 *sd = B->seed.as<u32>();
 
-    // Three streams: the device exposes four hardware queues to a process, streams that share a queue run one after the
-    // other, and the caller (its own stream, RCCL) needs one too.  Enqueue order = who gets wave slots first.
+    // Three streams (four for large batches, see below): the device exposes four hardware queues to a process, streams that
+    // share a queue run one after the other, and the caller (its own stream, RCCL) needs one too.  Enqueue order = who gets
+    // wave slots first.
     //   main     transcripts -> proof scalars -> multiscalar check -> verdict
     //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
     //   side 1   every other point of the batch (public keys included) -> signature points + hashing -> end of the signature hashes
@@ -559,18 +562,29 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
                        B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
     HIPCHK(ctx, tm.close("ledger_scan", s0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));             // ledger inputs and the senders' new ciphertexts are in place
-    // side 1: the bulk of the points (public keys included), then the signatures
+    // side 1: the bulk of the points, then the signatures.  Small batches are chains of short kernels and every stream beyond
+    // three may share a hardware queue with the caller's; large batches are bound by total work and gain more from the
+    // signatures starting at once on a stream of their own (side 2, with the public keys decoded there).
+    const bool own_sig_stream = n_txs >= SIG_STREAM_MIN_TXS;
+    hipStream_t ssig = own_sig_stream ? ctx->side[2] : s1;
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
+    if (own_sig_stream) {
+        HIPCHK(ctx, hipStreamWaitEvent(ssig, ctx->ev_setup, 0));
+        HIPCHK(ctx, tm.open("signatures", ssig));
+        launch_decode_list(ssig, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_keys, ssig));
+    }
     HIPCHK(ctx, tm.open("decode_rest", s1));
-    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok);
+    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), nullptr, n_dec, hb.n_static, pts, ok, !own_sig_stream);
     HIPCHK(ctx, tm.close("decode_rest", s1));
+    if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_keys, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s1));             // every point that is not the ledger scan's
-    HIPCHK(ctx, tm.open("signatures", s1));
-    launch_blake3_preimages(s1, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
-    launch_sig_point_absorb(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>(), B->sig_state.as<u64>());
-    launch_sig_final(s1, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
-    HIPCHK(ctx, tm.close("signatures", s1));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], s1));
+    if (!own_sig_stream) HIPCHK(ctx, tm.open("signatures", ssig));
+    launch_blake3_preimages(ssig, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
+    launch_sig_point_absorb(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>(), B->sig_state.as<u64>());
+    launch_sig_final(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
+    HIPCHK(ctx, tm.close("signatures", ssig));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], ssig));
     // main: proof scalars (sigma terms, range-proof terms, per-transaction range-proof context)
     HIPCHK(ctx, tm.mark("proof_scalars", st));
     {
