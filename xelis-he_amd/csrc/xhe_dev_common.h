@@ -81,17 +81,62 @@ __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setpri
 // priority) have slack until the verdict
 __device__ __forceinline__ void wave_priority_mid() { __builtin_amdgcn_s_setprio(1); }
 
-// 64-bit rotate left by a constant as two v_alignbit_b32 (the generic shift/or form costs two 64-bit shifts and two ORs)
+// 64-bit rotate left by a constant on a (lo, hi) pair of 32-bit halves: two v_alignbit_b32
 template <int N>
-__device__ __forceinline__ u64 rotl64c(u64 x) {
+__device__ __forceinline__ void rotl64_halves(u32 &out_lo, u32 &out_hi, u32 lo, u32 hi) {
     static_assert(N > 0 && N < 64, "rotation count");
-    u32 lo = (u32)x, hi = (u32)(x >> 32);
     if (N >= 32) { u32 t = lo; lo = hi; hi = t; }
     constexpr int R = N & 31;
-    if (R == 0) return (u64)lo | ((u64)hi << 32);
-    u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
-    return (u64)nl | ((u64)nh << 32);
+    if (R == 0) { out_lo = lo; out_hi = hi; return; }
+    out_hi = __builtin_amdgcn_alignbit(hi, lo, 32 - R);
+    out_lo = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
 }
+template <int N>
+__device__ __forceinline__ u64 rotl64c(u64 x) {
+    u32 lo, hi;
+    rotl64_halves<N>(lo, hi, (u32)x, (u32)(x >> 32));
+    return (u64)lo | ((u64)hi << 32);
+}
+// One round of Keccak-f[1600] on one 32-bit half-plane pair.  The state is kept as 2 x 25 32-bit words so that every
+// three-input boolean expression (the five-way column parities, chi's a ^ (~b & c)) is one v_bitop3_b32; written on
+// 64-bit words the same expressions compile to two-input operations.
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+#define XHE_KECCAK_RHO_PI(DST, SRC, N) rotl64_halves<N>(bl[DST], bh[DST], al[SRC], ah[SRC])
+__device__ __forceinline__ void keccak_round_halves(u32 (&al)[25], u32 (&ah)[25], u32 rc_lo, u32 rc_hi) {
+    u32 cl[5], ch[5], dl[5], dh[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        cl[x] = xor3(xor3(al[x], al[x + 5], al[x + 10]), al[x + 15], al[x + 20]);
+        ch[x] = xor3(xor3(ah[x], ah[x + 5], ah[x + 10]), ah[x + 15], ah[x + 20]);
+    }
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        u32 rl, rh;
+        rotl64_halves<1>(rl, rh, cl[(x + 1) % 5], ch[(x + 1) % 5]);
+        dl[x] = cl[(x + 4) % 5] ^ rl;
+        dh[x] = ch[(x + 4) % 5] ^ rh;
+    }
+#pragma unroll
+    for (int i = 0; i < 25; i++) { al[i] ^= dl[i % 5]; ah[i] ^= dh[i % 5]; }
+    u32 bl[25], bh[25];
+    bl[0] = al[0]; bh[0] = ah[0];
+    XHE_KECCAK_RHO_PI(10, 1, 1);   XHE_KECCAK_RHO_PI(20, 2, 62);  XHE_KECCAK_RHO_PI(5, 3, 28);   XHE_KECCAK_RHO_PI(15, 4, 27);
+    XHE_KECCAK_RHO_PI(16, 5, 36);  XHE_KECCAK_RHO_PI(1, 6, 44);   XHE_KECCAK_RHO_PI(11, 7, 6);   XHE_KECCAK_RHO_PI(21, 8, 55);
+    XHE_KECCAK_RHO_PI(6, 9, 20);   XHE_KECCAK_RHO_PI(7, 10, 3);   XHE_KECCAK_RHO_PI(17, 11, 10); XHE_KECCAK_RHO_PI(2, 12, 43);
+    XHE_KECCAK_RHO_PI(12, 13, 25); XHE_KECCAK_RHO_PI(22, 14, 39); XHE_KECCAK_RHO_PI(23, 15, 41); XHE_KECCAK_RHO_PI(8, 16, 45);
+    XHE_KECCAK_RHO_PI(18, 17, 15); XHE_KECCAK_RHO_PI(3, 18, 21);  XHE_KECCAK_RHO_PI(13, 19, 8);  XHE_KECCAK_RHO_PI(14, 20, 18);
+    XHE_KECCAK_RHO_PI(24, 21, 2);  XHE_KECCAK_RHO_PI(9, 22, 61);  XHE_KECCAK_RHO_PI(19, 23, 56); XHE_KECCAK_RHO_PI(4, 24, 14);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5) {
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            al[y + x] = bl[y + x] ^ (~bl[y + (x + 1) % 5] & bl[y + (x + 2) % 5]);
+            ah[y + x] = bh[y + x] ^ (~bh[y + (x + 1) % 5] & bh[y + (x + 2) % 5]);
+        }
+    }
+    al[0] ^= rc_lo; ah[0] ^= rc_hi;
+}
+#undef XHE_KECCAK_RHO_PI
 // Keccak-f[1600] on 25 words that stay in registers (every index is a compile-time constant)
 __device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
     const u64 RC[24] = {
@@ -101,33 +146,13 @@ __device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
         0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
         0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    u32 al[25], ah[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) { al[i] = (u32)a[i]; ah[i] = (u32)(a[i] >> 32); }
 #pragma unroll 1
-    for (int round = 0; round < 24; round++) {
-        u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
-        u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
-        u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
-        u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
-        u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
-        u64 d0 = c4 ^ rotl64c<1>(c1), d1 = c0 ^ rotl64c<1>(c2), d2 = c1 ^ rotl64c<1>(c3), d3 = c2 ^ rotl64c<1>(c4), d4 = c3 ^ rotl64c<1>(c0);
+    for (int round = 0; round < 24; round++) keccak_round_halves(al, ah, (u32)RC[round], (u32)(RC[round] >> 32));
 #pragma unroll
-        for (int y = 0; y < 25; y += 5) { a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4; }
-        u64 b[25];
-        b[0] = a[0];
-        b[10] = rotl64c<1>(a[1]);   b[20] = rotl64c<62>(a[2]);  b[5] = rotl64c<28>(a[3]);   b[15] = rotl64c<27>(a[4]);
-        b[16] = rotl64c<36>(a[5]);  b[1] = rotl64c<44>(a[6]);   b[11] = rotl64c<6>(a[7]);   b[21] = rotl64c<55>(a[8]);  b[6] = rotl64c<20>(a[9]);
-        b[7] = rotl64c<3>(a[10]);   b[17] = rotl64c<10>(a[11]); b[2] = rotl64c<43>(a[12]);  b[12] = rotl64c<25>(a[13]); b[22] = rotl64c<39>(a[14]);
-        b[23] = rotl64c<41>(a[15]); b[8] = rotl64c<45>(a[16]);  b[18] = rotl64c<15>(a[17]); b[3] = rotl64c<21>(a[18]);  b[13] = rotl64c<8>(a[19]);
-        b[14] = rotl64c<18>(a[20]); b[24] = rotl64c<2>(a[21]);  b[9] = rotl64c<61>(a[22]);  b[19] = rotl64c<56>(a[23]); b[4] = rotl64c<14>(a[24]);
-#pragma unroll
-        for (int y = 0; y < 25; y += 5) {
-            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
-            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
-            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
-            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
-            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
-        }
-        a[0] ^= RC[round];
-    }
+    for (int i = 0; i < 25; i++) a[i] = (u64)al[i] | ((u64)ah[i] << 32);
 }
 
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }

@@ -25,7 +25,7 @@
 #include <stdlib.h>
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
-#include "xhe_quad.h"
+#include "xhe_wide.h"
 
 namespace xhe {
 
@@ -500,22 +500,22 @@ __global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict
     if (lane == 0) ge_store(win_out + 32ull * w, R);
 }
 
-// Horner over the windows, most significant first.  The 252 doublings are one dependent chain, so one quad
-// of lanes shares the point (xhe_quad.h): a doubling costs one squaring and one multiplication per lane.
+// Horner over the windows, most significant first.  The 252 doublings are one dependent chain, so the whole
+// wavefront shares the point (xhe_wide.h: a lane per limb): a doubling is two ten-step products.
 // Writes the identity flag and, when out_words is not null, the compressed result.
 __global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, msm_plan p, const u32 *__restrict__ extra_point /*may be null*/,
                                                    u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag) {
     wave_priority_high();
-    if (threadIdx.x >= 4) return;
-    const u32 role = qd_role();
-    qd_point R = qd_load(win + 32ull * (p.W - 1), role);
+    const wd_lane L = wd_lane_init();
+    wd_point R = wd_load(win + 32ull * (p.W - 1), L);
     for (int w = (int)p.W - 2; w >= 0; w--) {
+        wd_cached q = wd_to_cached(wd_load(win + 32ull * w, L), L);       // off the chain: overlaps the doublings
 #pragma unroll 1
-        for (u32 k = 0; k < p.c; k++) R = qd_double(R, role);
-        R = qd_add(R, qd_load(win + 32ull * w, role), role);
+        for (u32 k = 0; k < p.c; k++) R = wd_double(R, L);
+        R = wd_add(R, q, L);
     }
-    if (extra_point) R = qd_add(R, qd_load(extra_point, role), role);
-    ge full = qd_gather(R);
+    if (extra_point) R = wd_add(R, wd_to_cached(wd_load(extra_point, L), L), L);
+    ge full = wd_gather(R);
     bool ident = ge_ristretto_is_identity(full);
     if (out_words) {
         u32 enc[8]; ristretto_encode_words(enc, full);

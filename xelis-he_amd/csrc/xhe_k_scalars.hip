@@ -199,7 +199,7 @@ __device__ __forceinline__ void rp_prep_terms(u32 i, const u8 *__restrict__ byte
 // One launch for the scalars of all three proof kinds (they only need the transcript's challenges and are independent
 // of each other): blocks [0, b_cm) take commitment-equality proofs, [b_cm, b_cm + b_xf) ciphertext-validity proofs, the
 // rest one transaction's range proof per thread.  gh[]: per proof / per transaction the contributions to B and H.
-__global__ void __launch_bounds__(64) k_proof_scalars(proof_scalar_args a) {
+__global__ void __launch_bounds__(64, 2) k_proof_scalars(proof_scalar_args a) {
     wave_priority_high();
     const u32 b_cm = (a.n_cm + 63) / 64, b_xf = (a.n_xf + 63) / 64;
     u32 blk = blockIdx.x;
