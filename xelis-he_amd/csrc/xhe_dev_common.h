@@ -38,21 +38,6 @@ __device__ __forceinline__ sc load_sc_limbs(const u32 *__restrict__ src) {
 }
 __device__ __forceinline__ void raise_err(u32 *tx_err, u32 tx, u32 key) { atomicMin(&tx_err[tx], key); }
 
-// batch factor: Keccak-f over (seed, domain, index), 64 bytes reduced mod l
-__device__ __forceinline__ sc prf_scalar(const u32 *__restrict__ seed8, u32 domain, u64 index) {
-    u64 st[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) st[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) st[i] = (u64)seed8[2 * i] | ((u64)seed8[2 * i + 1] << 32);
-    st[4] = index; st[5] = domain; st[6] = 0x1f; st[16] = 0x8000000000000000ULL;
-    keccak_f1600(st);
-    u32 w[16];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { w[2 * i] = (u32)st[i]; w[2 * i + 1] = (u32)(st[i] >> 32); }
-    return sc_from_wide_words(w);
-}
-
 __device__ __forceinline__ ge ge_from_niels_affine(const ge_niels &q) {
     // x = (ypx - ymx)/2, y = (ypx + ymx)/2
     fe inv2 = fe_zero();            // (p+1)/2 = 2^254 - 9
@@ -153,6 +138,36 @@ __device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
     for (int round = 0; round < 24; round++) keccak_round_halves(al, ah, (u32)RC[round], (u32)(RC[round] >> 32));
 #pragma unroll
     for (int i = 0; i < 25; i++) a[i] = (u64)al[i] | ((u64)ah[i] << 32);
+}
+
+// Batch factors: scalar(s) = wide-reduce(Keccak-f[1600](seed || index || domain || SHAKE padding)) -- one permutation
+// yields up to two scalars (128 of the 136 rate bytes).
+__device__ __forceinline__ void prf_state(u64 (&st)[25], const u32 *__restrict__ seed8, u32 domain, u64 index) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) st[i] = (u64)seed8[2 * i] | ((u64)seed8[2 * i + 1] << 32);
+    st[4] = index; st[5] = domain; st[6] = 0x1f; st[16] = 0x8000000000000000ULL;
+    keccak_f1600_regs(st);
+}
+__device__ __forceinline__ sc prf_scalar(const u32 *__restrict__ seed8, u32 domain, u64 index) {
+    u64 st[25];
+    prf_state(st, seed8, domain, index);
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w[2 * i] = (u32)st[i]; w[2 * i + 1] = (u32)(st[i] >> 32); }
+    return sc_from_wide_words(w);
+}
+__device__ __forceinline__ void prf_scalar_pair(sc &first, sc &second, const u32 *__restrict__ seed8, u32 domain, u64 index) {
+    u64 st[25];
+    prf_state(st, seed8, domain, index);
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w[2 * i] = (u32)st[i]; w[2 * i + 1] = (u32)(st[i] >> 32); }
+    first = sc_from_wide_words(w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w[2 * i] = (u32)st[8 + i]; w[2 * i + 1] = (u32)(st[8 + i] >> 32); }
+    second = sc_from_wide_words(w);
 }
 
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }

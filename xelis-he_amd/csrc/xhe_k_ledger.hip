@@ -6,35 +6,30 @@
 namespace xhe {
 
 // ---- ledger scan -----------------------------------------------------------------------------------
-struct ct_acc { ge C, D; };
-__device__ __forceinline__ ct_acc ct_identity() { ct_acc a; a.C = ge_identity(); a.D = ge_identity(); return a; }
-__device__ __forceinline__ ct_acc ct_add(const ct_acc &a, const ct_acc &b) { ct_acc r; r.C = ge_add(a.C, b.C); r.D = ge_add(a.D, b.D); return r; }
-__device__ __forceinline__ void ct_store(u32 *dst, const ct_acc &a) { ge_store(dst, a.C); ge_store(dst + 32, a.D); }
-__device__ __forceinline__ ct_acc ct_load(const u32 *src) { ct_acc a; a.C = ge_load(src); a.D = ge_load(src + 32); return a; }
-
-__device__ __forceinline__ void scan_apply_op(ct_acc &acc, const dev_op &op, const u32 *__restrict__ pts, const u32 *__restrict__ gtab) {
-    if (op.kind == 2) {
+// A ciphertext is two points (commitment C, handle D) whose sums never mix, so every kernel of the scan runs as two
+// independent halves (blockIdx.y = 0 for C, 1 for D): half the dependent additions per thread.  All buffers keep a
+// ciphertext as 64 words, C then D.
+__device__ __forceinline__ void scan_apply_op(ge &acc, const dev_op &op, u32 which, const u32 *__restrict__ pts, const u32 *__restrict__ gtab) {
+    if (op.kind == 2) {                               // minus amount * G: the commitment only
+        if (which) return;
         u64 a = op.amount;
 #pragma unroll 1
         for (u32 w = 0; w < 8 && a; w++, a >>= 8) {
             u32 b = (u32)a & 255;
-            if (b) acc.C = ge_msub(acc.C, ge_niels_load(gtab + 32ull * (w * 256 + b)));
+            if (b) acc = ge_msub(acc, ge_niels_load(gtab + 32ull * (w * 256 + b)));
         }
     } else {
-        bool neg = op.kind == 1;
-        acc.C = ge_madd_signed(acc.C, ge_niels_load(pts + 32ull * op.c_pt), neg);
-        acc.D = ge_madd_signed(acc.D, ge_niels_load(pts + 32ull * op.d_pt), neg);
+        acc = ge_madd_signed(acc, ge_niels_load(pts + 32ull * (which ? op.d_pt : op.c_pt)), op.kind == 1);
     }
 }
 
-
-// inclusive Hillis-Steele scan of one ct per thread through LDS; returns the inclusive value of thread t
-__device__ __forceinline__ ct_acc block_scan_ct(ct_acc v, u32 *lds /* SCAN_BLOCK * 64 words */) {
+// inclusive Hillis-Steele scan of one point per thread through LDS; returns the inclusive value of thread t
+__device__ __forceinline__ ge block_scan_ge(ge v, u32 *lds /* SCAN_BLOCK * 32 words */) {
     u32 t = threadIdx.x;
     for (u32 d = 1; d < SCAN_BLOCK; d <<= 1) {
-        ct_store(lds + 64 * t, v);
+        ge_store(lds + 32 * t, v);
         __syncthreads();
-        if (t >= d) { ct_acc o = ct_load(lds + 64 * (t - d)); v = ct_add(o, v); }
+        if (t >= d) { ge o = ge_load(lds + 32 * (t - d)); v = ge_add(o, v); }
         __syncthreads();
     }
     return v;
@@ -44,38 +39,38 @@ __device__ __forceinline__ ct_acc block_scan_ct(ct_acc v, u32 *lds /* SCAN_BLOCK
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_local(const dev_op *__restrict__ ops, u32 n_ops, const u32 *__restrict__ pts, const u32 *__restrict__ gtab,
                                                            u32 *__restrict__ thread_excl, u32 *__restrict__ block_tot) {
     wave_priority_high();
-    __shared__ u32 lds[SCAN_BLOCK * 64];
-    u32 t = threadIdx.x, gt = blockIdx.x * SCAN_BLOCK + t;
-    ct_acc acc = ct_identity();
+    __shared__ u32 lds[SCAN_BLOCK * 32];
+    const u32 t = threadIdx.x, gt = blockIdx.x * SCAN_BLOCK + t, which = blockIdx.y;
+    ge acc = ge_identity();
     for (u32 k = 0; k < SCAN_K; k++) {
         u32 o = gt * SCAN_K + k;
-        if (o < n_ops) scan_apply_op(acc, ops[o], pts, gtab);
+        if (o < n_ops) scan_apply_op(acc, ops[o], which, pts, gtab);
     }
-    ct_acc incl = block_scan_ct(acc, lds);
+    ge incl = block_scan_ge(acc, lds);
     // exclusive = inclusive of the previous thread
-    ct_store(lds + 64 * t, incl);
+    ge_store(lds + 32 * t, incl);
     __syncthreads();
-    ct_acc excl = t ? ct_load(lds + 64 * (t - 1)) : ct_identity();
-    ct_store(thread_excl + 64ull * gt, excl);
-    if (t == SCAN_BLOCK - 1) ct_store(block_tot + 64ull * blockIdx.x, incl);
+    ge excl = t ? ge_load(lds + 32 * (t - 1)) : ge_identity();
+    ge_store(thread_excl + 64ull * gt + 32 * which, excl);
+    if (t == SCAN_BLOCK - 1) ge_store(block_tot + 64ull * blockIdx.x + 32 * which, incl);
 }
-// phase 2: one block turns the block totals into exclusive block prefixes (in place)
+// phase 2: one block per half turns the block totals into exclusive block prefixes (in place)
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(u32 *__restrict__ block_tot, u32 n_blocks) {
     wave_priority_high();
-    __shared__ u32 lds[SCAN_BLOCK * 64];
-    u32 t = threadIdx.x;
+    __shared__ u32 lds[SCAN_BLOCK * 32];
+    const u32 t = threadIdx.x, which = blockIdx.y;
     u32 per = (n_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32 lo = t * per, hi = lo + per; if (hi > n_blocks) hi = n_blocks;
-    ct_acc acc = ct_identity();
-    for (u32 b = lo; b < hi; b++) acc = ct_add(acc, ct_load(block_tot + 64ull * b));
-    ct_acc incl = block_scan_ct(acc, lds);
-    ct_store(lds + 64 * t, incl);
+    ge acc = ge_identity();
+    for (u32 b = lo; b < hi; b++) acc = ge_add(acc, ge_load(block_tot + 64ull * b + 32 * which));
+    ge incl = block_scan_ge(acc, lds);
+    ge_store(lds + 32 * t, incl);
     __syncthreads();
-    ct_acc run = t ? ct_load(lds + 64 * (t - 1)) : ct_identity();
+    ge run = t ? ge_load(lds + 32 * (t - 1)) : ge_identity();
     for (u32 b = lo; b < hi; b++) {
-        ct_acc v = ct_load(block_tot + 64ull * b);
-        ct_store(block_tot + 64ull * b, run);
-        run = ct_add(run, v);
+        ge v = ge_load(block_tot + 64ull * b + 32 * which);
+        ge_store(block_tot + 64ull * b + 32 * which, run);
+        run = ge_add(run, v);
     }
 }
 // phase 3: global inclusive prefixes at the operations that need them
@@ -84,17 +79,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const dev_op *__restr
                                                            const u32 *__restrict__ slot_last_op, u32 *__restrict__ slot_base, u32 *__restrict__ slot_final,
                                                            u32 *__restrict__ emit_incl) {
     wave_priority_high();
-    u32 gt = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const u32 gt = blockIdx.x * SCAN_BLOCK + threadIdx.x, which = blockIdx.y, h = 32 * which;
     if (gt * SCAN_K >= n_ops) return;
-    ct_acc acc = ct_add(ct_load(block_excl + 64ull * blockIdx.x), ct_load(thread_excl + 64ull * gt));
+    ge acc = ge_add(ge_load(block_excl + 64ull * blockIdx.x + h), ge_load(thread_excl + 64ull * gt + h));
     for (u32 k = 0; k < SCAN_K; k++) {
         u32 o = gt * SCAN_K + k;
         if (o >= n_ops) break;
         dev_op op = ops[o];
-        if (op.first) ct_store(slot_base + 64ull * op.slot, acc);          // prefix before the slot's initial balance
-        scan_apply_op(acc, op, pts, gtab);
-        if (op.emit != 0xffffffffu) ct_store(emit_incl + 64ull * op.emit, acc);
-        if (slot_last_op[op.slot] == o) ct_store(slot_final + 64ull * op.slot, acc);
+        if (op.first) ge_store(slot_base + 64ull * op.slot + h, acc);          // prefix before the slot's initial balance
+        scan_apply_op(acc, op, which, pts, gtab);
+        if (op.emit != 0xffffffffu) ge_store(emit_incl + 64ull * op.emit + h, acc);
+        if (slot_last_op[op.slot] == o) ge_store(slot_final + 64ull * op.slot + h, acc);
     }
 }
 // phase 4a: sender ciphertexts read by the equality proofs, as affine-Niels points
@@ -126,9 +121,9 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
                         u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok) {
     if (!n_ops) return;
     u32 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, block_tot, scan_blocks);
-    hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot, slot_last_op, slot_base, slot_final,
+    hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks, 2), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1, 2), dim3(SCAN_BLOCK), 0, st, block_tot, scan_blocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks, 2), dim3(SCAN_BLOCK), 0, st, ops, n_ops, pts_in, gtab, thread_excl, block_tot, slot_last_op, slot_base, slot_final,
                        emit_incl);
     if (n_emit) hipLaunchKernelGGL(k_scan_emit, dim3(grid_for(2 * n_emit, 256)), dim3(256), 0, st, emit_incl, emit_slot, slot_base, n_emit, emit_pt_base, pts, ok);
 }

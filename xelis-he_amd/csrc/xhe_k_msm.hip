@@ -272,6 +272,37 @@ __global__ void __launch_bounds__(512) k_msm_coarse_scatter(const unsigned short
         }
     }
 }
+// One workgroup: per (window, coarse bin) the tiles' counts become the count of the earlier tiles, and the bins' totals
+// are scanned into coarse_off[W * nb + 1].  A few thousand bins at most, so one launch replaces the three of the
+// general prefix + scan (each launch boundary on the stream costs 10-20 us here, more than the work).
+__global__ void __launch_bounds__(1024) k_msm_bin_offsets(u32 *__restrict__ tile_hist, u32 n_bins, u32 nb, u32 tiles, u32 *__restrict__ coarse_off) {
+    wave_priority_high();
+    __shared__ u32 wave_sum[16];
+    __shared__ u32 base_sh;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base_sh = 0;
+    __syncthreads();
+    for (u32 g0 = 0; g0 < n_bins; g0 += 1024) {
+        u32 g = g0 + t, run = 0;
+        if (g < n_bins) {
+            u32 w = g / nb, b = g % nb;
+            u32 *col = tile_hist + (u64)w * tiles * nb + b;
+            for (u32 k = 0; k < tiles; k++) { u32 v = col[(u64)k * nb]; col[(u64)k * nb] = run; run += v; }
+        }
+        u32 incl = run;                               // inclusive scan over the workgroup: inside the wave, then over the 16 wave sums
+#pragma unroll
+        for (u32 d = 1; d < 64; d <<= 1) { u32 o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        u32 before = base_sh;
+        for (u32 k = 0; k < wave; k++) before += wave_sum[k];
+        if (g < n_bins) coarse_off[g] = before + incl - run;
+        __syncthreads();
+        if (t == 1023) base_sh = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) coarse_off[n_bins] = base_sh;
+}
 // workgroup per (coarse bin, window): bucket offsets of the bin's 2^f buckets and the entries in bucket order
 __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ tmp, const u32 *__restrict__ coarse_off, msm_plan p, u32 *__restrict__ offsets,
                                                        u32 *__restrict__ sorted, u64 cap) {
@@ -607,11 +638,8 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
         msm_plan q = p; q.B = p.B >> p.fine_bits;      // the coarse bins play the buckets' part in the prefix and scan kernels
         const u32 n_bins = p.W * q.B;
         hipLaunchKernelGGL(k_msm_coarse_hist, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist);
-        hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_bins, 256)), dim3(256), 0, st, ws.tile_hist, q, tiles, ws.hist);
         MARK("msm_scan");
-        u32 scan_tiles = (n_bins + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, n_bins, ws.segs);
-        hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, n_bins, ws.segs, ws.coarse);
+        hipLaunchKernelGGL(k_msm_bin_offsets, dim3(1), dim3(1024), 0, st, ws.tile_hist, n_bins, q.B, tiles, ws.coarse);
         MARK("msm_scatter");
         hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap);
         hipLaunchKernelGGL(k_msm_fine_sort, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);

@@ -101,7 +101,10 @@ static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_
                      RPC_Y2 = 37 /* 16 */, RPC_E = 53 /* 16 */;
 static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 
-__device__ __forceinline__ void rp_prep_terms(u32 i, const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const dev_cm *__restrict__ cms,
+// Two threads per proof (in different workgroups, so control flow stays uniform): `side` 0 computes the scalars of the
+// L_j and R_j and the per-bit tables of the context, side 1 everything else.  Both need y^(nm-1) and prod u_j^2 and
+// derive them themselves (two short chains) rather than wait for each other.
+__device__ __forceinline__ void rp_prep_terms(u32 i, u32 side, const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const dev_cm *__restrict__ cms,
                                               const dev_xfer *__restrict__ xfers, const u32 *__restrict__ chal, const u32 *__restrict__ seed,
                                               u32 *__restrict__ scalars, u32 *__restrict__ term_point, u32 *__restrict__ rp_ctx, u32 *__restrict__ gh,
                                               u32 *__restrict__ rp_err) {
@@ -109,50 +112,42 @@ __device__ __forceinline__ void rp_prep_terms(u32 i, const u8 *__restrict__ byte
     const u32 lg = d.lg, A = d.n_commitments, T = d.n_transfers;
     const u32 n_dyn = 4 + 2 * lg + A + T;
     u32 *s = scalars + 8ull * d.rp_term_off;
-    u32 *tp = term_point + d.rp_term_off;
-    // term -> point map is valid whatever happens below
-    for (u32 k = 0; k < 4 + 2 * lg; k++) tp[k] = d.rp_pt + k;
-    for (u32 k = 0; k < A; k++) tp[4 + 2 * lg + k] = cms[d.cm_first + k].pt;
-    for (u32 k = 0; k < T; k++) tp[4 + 2 * lg + A + k] = xfers[d.xfer_first + k].pt;
-    bool valid = lg >= 6 && lg <= 15 && (64ull * d.m == (1ull << lg)) && d.m <= 512;
+    const bool valid = lg >= 6 && lg <= 15 && (64ull * d.m == (1ull << lg)) && d.m <= 512;
+    if (side == 0) {
+        u32 *tp = term_point + d.rp_term_off;
+        // term -> point map is valid whatever happens below
+        for (u32 k = 0; k < 4 + 2 * lg; k++) tp[k] = d.rp_pt + k;
+        for (u32 k = 0; k < A; k++) tp[4 + 2 * lg + k] = cms[d.cm_first + k].pt;
+        for (u32 k = 0; k < T; k++) tp[4 + 2 * lg + A + k] = xfers[d.xfer_first + k].pt;
+    }
     if (!valid) {
-        rp_err[i] = 1;
-        for (u32 k = 0; k < 8 * n_dyn; k++) s[k] = 0;
-        store_sc_limbs(gh + 18ull * i, sc_zero()); store_sc_limbs(gh + 18ull * i + 9, sc_zero());
+        if (side == 0) { for (u32 k = 0; k < 8 * n_dyn; k++) s[k] = 0; }
+        else { rp_err[i] = 1; store_sc_limbs(gh + 18ull * i, sc_zero()); store_sc_limbs(gh + 18ull * i + 9, sc_zero()); }
         return;
     }
     const u8 *rp = bytes + d.rec + d.rp_off;
     const u32 *ch = chal + 8ull * (d.chal_off + 2 * A + 2 * T);
-    sc y = load_scalar_words(ch), z = load_scalar_words(ch + 8), x = load_scalar_words(ch + 16), w = load_scalar_words(ch + 24);
-    sc t_x = load_scalar_bytes(rp + 128), t_x_bl = load_scalar_bytes(rp + 160), e_bl = load_scalar_bytes(rp + 192);
-    sc a = load_scalar_bytes(rp + 224 + 64 * lg), b = load_scalar_bytes(rp + 224 + 64 * lg + 32);
-    sc rho = prf_scalar(seed, 3, i), c = prf_scalar(seed, 4, i);
+    const sc y = load_scalar_words(ch);
+    sc rho, c;
+    prf_scalar_pair(rho, c, seed, 3, i);
     u32 *ctx = rp_ctx + 9ull * RPC_SCALARS * i;
 
-    // powers of y, the sum of the y^i as the product of (1 + y^(2^k)), Yt = y^(nm-1)
-    sc sum_y = sc_one(), yt = sc_one();
-    {
-        sc q = y;
-        for (u32 k = 0; k < lg; k++) {
-            store_sc_limbs(ctx + 9 * (RPC_Y2 + k), q);
-            sum_y = sc_mul(sum_y, sc_add(sc_one(), q)); yt = sc_mul(yt, q);
-            q = sc_mul(q, q);
+    if (side == 0) {
+        // powers of y, Yt = y^(nm-1)
+        sc yt = sc_one();
+        {
+            sc q = y;
+            for (u32 k = 0; k < lg; k++) { store_sc_limbs(ctx + 9 * (RPC_Y2 + k), q); yt = sc_mul(yt, q); q = sc_mul(q, q); }
         }
-    }
-    // squares of the u_j: prefix products left to right, then suffix products on the way back
-    sc u2[16], pre[17];
-    sc U = sc_one();
-    pre[0] = sc_one();
-    for (u32 j = 0; j < lg; j++) {
-        sc u = load_scalar_words(ch + 32 + 8 * j);
-        U = sc_mul(U, u);
-        u2[j] = sc_mul(u, u);
-        pre[j + 1] = sc_mul(pre[j], u2[j]);
-    }
-    const sc UU = pre[lg];                            // U^2
-    const sc rho_yt = sc_mul(rho, yt), rho_k = sc_mul(rho_yt, UU);       // rho' = rho * kappa
-    const sc rho_kc = sc_mul(rho_k, c);
-    {
+        // squares of the u_j: prefix products left to right, then suffix products on the way back
+        sc u2[16], pre[17];
+        pre[0] = sc_one();
+        for (u32 j = 0; j < lg; j++) {
+            sc u = load_scalar_words(ch + 32 + 8 * j);
+            u2[j] = sc_mul(u, u);
+            pre[j + 1] = sc_mul(pre[j], u2[j]);
+        }
+        const sc rho_yt = sc_mul(rho, yt), rho_k = sc_mul(rho_yt, pre[lg]);       // rho' = rho * kappa
         sc suffix = rho_yt;                           // rho Yt prod_(k > j) u_k^2
         for (int j = (int)lg - 1; j >= 0; j--) {
             store_scalar_words(s + 8 * (4 + 2 * j), sc_mul(rho_k, u2[j]));               // L_j
@@ -162,12 +157,29 @@ __device__ __forceinline__ void rp_prep_terms(u32 i, const u8 *__restrict__ byte
             store_sc_limbs(ctx + 9 * (RPC_U2 + bit), u2[j]);
             store_sc_limbs(ctx + 9 * (RPC_YU + bit), sc_mul(u2[j], load_sc_limbs(ctx + 9 * (RPC_Y2 + bit))));
         }
+        return;
     }
+
+    const sc z = load_scalar_words(ch + 8), x = load_scalar_words(ch + 16), w = load_scalar_words(ch + 24);
+    const sc t_x = load_scalar_bytes(rp + 128), t_x_bl = load_scalar_bytes(rp + 160), e_bl = load_scalar_bytes(rp + 192);
+    const sc a = load_scalar_bytes(rp + 224 + 64 * lg), b = load_scalar_bytes(rp + 224 + 64 * lg + 32);
+    // the sum of the y^i as the product of (1 + y^(2^k)), Yt = y^(nm-1)
+    sc sum_y = sc_one(), yt = sc_one();
+    {
+        sc q = y;
+        for (u32 k = 0; k < lg; k++) { sum_y = sc_mul(sum_y, sc_add(sc_one(), q)); yt = sc_mul(yt, q); q = sc_mul(q, q); }
+    }
+    sc U = sc_one();
+    for (u32 j = 0; j < lg; j++) U = sc_mul(U, load_scalar_words(ch + 32 + 8 * j));
+    const sc UU = sc_mul(U, U);
+    const sc rho_k = sc_mul(sc_mul(rho, yt), UU);     // rho' = rho * kappa
+    const sc rho_kc = sc_mul(rho_k, c);
     sc zz = sc_mul(z, z);
+    const sc rho_kcx = sc_mul(rho_kc, x);
     store_scalar_words(s, rho_k);                                  // A
     store_scalar_words(s + 8, sc_mul(rho_k, x));                   // S
-    store_scalar_words(s + 16, sc_mul(rho_kc, x));                 // T_1
-    store_scalar_words(s + 24, sc_mul(sc_mul(rho_kc, x), x));      // T_2
+    store_scalar_words(s + 16, rho_kcx);                           // T_1
+    store_scalar_words(s + 24, sc_mul(rho_kcx, x));                // T_2
     {
         sc v = sc_mul(rho_kc, zz);
         for (u32 k = 0; k < A + T; k++) { store_scalar_words(s + 8 * (4 + 2 * lg + k), v); v = sc_mul(v, z); }
@@ -210,8 +222,9 @@ __global__ void __launch_bounds__(64, 2) k_proof_scalars(proof_scalar_args a) {
         u32 i = (blk - b_cm) * 64 + threadIdx.x;
         if (i < a.n_xf) sigma_xf_terms(i, a.bytes, a.xfers, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh + 18ull * a.n_cm);
     } else {
-        u32 i = (blk - b_cm - b_xf) * 64 + threadIdx.x;
-        if (i < a.n_txs) rp_prep_terms(i, a.bytes, a.txs, a.cms, a.xfers, a.chal, a.seed, a.scalars, a.term_point, a.rp_ctx, a.gh + 18ull * (a.n_cm + a.n_xf), a.rp_err);
+        u32 r = blk - b_cm - b_xf;                     // even workgroups: side 0, odd: side 1 of the same 64 transactions
+        u32 i = (r >> 1) * 64 + threadIdx.x;
+        if (i < a.n_txs) rp_prep_terms(i, r & 1, a.bytes, a.txs, a.cms, a.xfers, a.chal, a.seed, a.scalars, a.term_point, a.rp_ctx, a.gh + 18ull * (a.n_cm + a.n_xf), a.rp_err);
     }
 }
 
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh
 
 
 void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a) {
-    u32 blocks = (a.n_cm + 63) / 64 + (a.n_xf + 63) / 64 + (a.n_txs + 63) / 64;
+    u32 blocks = (a.n_cm + 63) / 64 + (a.n_xf + 63) / 64 + 2 * ((a.n_txs + 63) / 64);          // two workgroups per 64 range proofs
     if (blocks) hipLaunchKernelGGL(k_proof_scalars, dim3(blocks), dim3(64), 0, st, a);
 }
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out) {
