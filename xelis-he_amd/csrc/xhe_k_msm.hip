@@ -50,7 +50,19 @@ msm_plan msm_make_plan(u64 n) {
     while (M < 128 && 2ull * M <= per_bucket && entries / (2ull * M) >= 8192) M *= 2;
     if (M < 16 && entries >= (1u << 16)) M = 16;
     if (M < 32 && entries >= (1u << 20)) M = 32;
-    p.M = M;
+    // Every thread takes one chunk, and a chunk is ~M * 2000 instructions: when the chunks need a little more than a whole
+    // number of rounds of the chip's thread slots (256 CUs x 3 workgroups of 256 at this kernel's register count), the few
+    // workgroups of the last round run alone at a lone wave's rate - a third of the kernel's time at the bench size.  So the
+    // chunk grows until the chunks fit the rounds they need with a few per cent to spare.
+    {
+        const u64 slots = 256ull * 3 * 256;
+        u64 chunks = entries / M + 1, rounds = (chunks + slots - 1) / slots;
+        if (rounds <= 8) {
+            u64 fit = (entries + rounds * (slots - slots / 32) - 1) / (rounds * (slots - slots / 32));
+            if (fit > M && fit <= 2ull * M) M = (u32)fit;
+        }
+        p.M = M;
+    }
     // terms per workgroup of the counting sort: every workgroup reads and writes all B counters of its window, so a tile
     // holds at least two terms per bucket once there are enough tiles (tiles * W workgroups) to cover the chip
     p.tile = 8192;

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 static constexpr u32 DECODE_MAX_BLOCKS = 512;
 // list != null: a pass over the n listed entries (the points the ledger scan waits for, or the public keys);
 // list == null: all n entries except those whose mark (0 bulk, 1 ledger scan input, 2 public key) is set in skip_mask
-__global__ void __launch_bounds__(256, 3) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
+__global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok, u32 skip_mask) {
     if (list) wave_priority_high(); else wave_priority_mid();      // listed points head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
