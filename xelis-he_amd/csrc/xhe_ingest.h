@@ -35,7 +35,7 @@ static inline key32 make_key32(const u8 *p) { key32 k; memcpy(k.b, p, 32); retur
 
 struct host_batch {
     u64 n_txs = 0;
-    std::vector<u8> bytes;                 // records || account keys || balance cts || multisig signers
+    u64 bytes_len = 0, rec_bytes = 0, n_signer_keys = 0;      // device byte buffer: records || account keys || balance cts || multisig signers || spare
     u64 keys_base = 0, cts_base = 0, signers_base = 0;
     std::vector<dev_tx> txs;
     std::vector<dev_cm> cms;
@@ -96,11 +96,10 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     hb.cts_base = hb.keys_base + 32 * lv.n_accounts;
     u64 n_signers = lv.n_multisig ? lv.multisig_offsets[lv.n_multisig] : 0;
     hb.signers_base = hb.cts_base + 64 * lv.n_balances;
-    hb.bytes.assign(hb.signers_base + 32 * n_signers + 64, 0);
-    if (rec_bytes) memcpy(hb.bytes.data(), records, rec_bytes);
-    if (lv.n_accounts) memcpy(hb.bytes.data() + hb.keys_base, lv.account_keys, 32 * lv.n_accounts);
-    if (lv.n_balances) memcpy(hb.bytes.data() + hb.cts_base, lv.balance_cts, 64 * lv.n_balances);
-    if (n_signers) memcpy(hb.bytes.data() + hb.signers_base, lv.multisig_signers, 32 * n_signers);
+    // the device's byte buffer: records | account keys | ledger ciphertexts | multisig signer keys | 64 spare bytes.  It is
+    // assembled from the caller's arrays when the batch is uploaded (byte_pieces); no host copy is kept.
+    hb.rec_bytes = rec_bytes; hb.n_signer_keys = n_signers;
+    hb.bytes_len = hb.signers_base + 32 * n_signers + 64;
 
     // ---- ledger key structure ----
     std::unordered_map<key32, u32, byte_key_hash<32>> account_of;

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <chrono>
+#include <mutex>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -23,17 +24,66 @@ using namespace xhe;
 
 static std::string g_create_error;
 
+// Device blocks released by one batch are kept for the next: a batch takes two blocks (its uploaded tables, its
+// workspace), and in a steady stream of batches of similar size neither costs a hipMalloc / hipFree pair (each of which
+// is tens of microseconds and, for hipFree, a device-wide synchronisation).
+struct dev_pool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void *>> blocks;       // free blocks: capacity, pointer
+    size_t held = 0;
+    static constexpr size_t HOLD_MAX = 32ull << 30;      // beyond this the blocks go back to the driver
+    hipError_t take(size_t bytes, void **p, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = blocks.size();
+            for (size_t i = 0; i < blocks.size(); i++)
+                if (blocks[i].first >= bytes && blocks[i].first <= 2 * bytes + (1u << 20) && (best == blocks.size() || blocks[i].first < blocks[best].first)) best = i;
+            if (best != blocks.size()) {
+                *cap = blocks[best].first; *p = blocks[best].second; held -= *cap;
+                blocks.erase(blocks.begin() + (long)best);
+                return hipSuccess;
+            }
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(p, want);
+        if (e != hipSuccess) {                            // memory held for later may be what is missing now
+            drain();
+            e = hipMalloc(p, want);
+        }
+        if (e == hipSuccess) *cap = want;
+        return e;
+    }
+    void give(void *p, size_t cap) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (held + cap > HOLD_MAX) { (void)hipFree(p); return; }
+        blocks.push_back({cap, p}); held += cap;
+    }
+    void drain() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &b : blocks) (void)hipFree(b.second);
+        blocks.clear(); held = 0;
+    }
+};
+
 struct dev_buf {
     void *p = nullptr; size_t cap = 0;
+    dev_pool *pool = nullptr;                            // where the block comes from and goes back to (null: the driver)
+    bool view = false;                                   // a range inside another buffer: nothing to free
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        if (view) return hipErrorInvalidValue;
+        release();
+        if (pool) return pool->take(bytes, &p, &cap);
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void point_at(void *base, size_t off, size_t bytes) { p = (char *)base + off; cap = bytes; view = true; }
+    void release() {
+        if (p && !view) { if (pool) pool->give(p, cap); else (void)hipFree(p); }
+        p = nullptr; cap = 0; view = false;
+    }
     template <typename T> T *as() const { return (T *)p; }
 };
 
@@ -93,6 +143,7 @@ struct stage_timer {
     void release() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
 };
 
+static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory per context, at most
 static constexpr u32 SIG_STREAM_MIN_TXS = 32768;     // from this batch size on the signatures get a stream of their own
 
 struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
@@ -105,6 +156,8 @@ struct xhe_ctx {
     hipEvent_t ev_keys = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     std::string error;
     stage_timer timer;
+    dev_pool pool;                 // blocks of freed batches
+    void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
     // level-0 workspace
     dev_buf in_bytes, scalars, niels, ok, result, xyzt;
     msm_workspace msm;
@@ -126,12 +179,13 @@ struct xhe_batch {
     dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
+    dev_buf arena_up, arena_ws;   // the two blocks every buffer above is a range of: uploaded tables, workspace
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
         for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
-                           &slot_final, &emit_incl, &final_cts, &verdict, &seed})
+                           &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws})
             b->release();
     }
 };
@@ -210,14 +264,6 @@ static int32_t ensure_tables(xhe_ctx *ctx, u32 cap) {
     return 0;
 }
 
-template <typename T>
-static hipError_t upload_vec(dev_buf &b, const std::vector<T> &v, hipStream_t st) {
-    hipError_t e = b.reserve(std::max<size_t>(v.size() * sizeof(T), 64));
-    if (e != hipSuccess) return e;
-    if (v.empty()) return hipSuccess;
-    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
-}
-
 static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]);
 
 extern "C" {
@@ -247,6 +293,8 @@ void xhe_destroy(xhe_ctx *ctx) {
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
+    ctx->pool.drain();
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     ctx->timer.release();
     for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
@@ -340,8 +388,10 @@ void xhe_batch_free(xhe_ctx *ctx, xhe_batch *b) {
     delete b;
 }
 
-int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
-                         xhe_verdict *structural) {
+// wait_for_copies = false leaves the table copies in flight on the main stream: the caller must synchronise that stream before
+// the next upload on this context (which reuses the pinned staging memory) - xhe_verify_batch does, by verifying.
+static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
+                                 xhe_verdict *structural, bool wait_for_copies) {
     if (!ctx || !offsets || !in || !batch_out || (n_txs && !records)) return XHE_E_ARG;
     if (n_txs > 0x7ffffff0ull) return XHE_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -372,18 +422,42 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     std::vector<u32> group_txs; B->group_off.assign(17, 0);
     for (u32 lg = 0; lg < 16; lg++) { B->group_off[lg] = (u32)group_txs.size(); group_txs.insert(group_txs.end(), hb.lg_groups[lg].begin(), hb.lg_groups[lg].end()); }
     B->group_off[16] = (u32)group_txs.size();
-#define UP(buf, vec) do { hipError_t e_ = upload_vec(B->buf, vec, st); if (e_ != hipSuccess) { set_error(ctx, std::string("upload " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
-    UP(bytes, hb.bytes); UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
+    // One device block for every uploaded table and one for the workspace; every buffer of the batch is a 256-byte aligned
+    // range of one of them.  The tables are assembled in the context's pinned staging memory and cross in one copy (in
+    // slices when they exceed it).
+    B->arena_up.pool = &ctx->pool; B->arena_ws.pool = &ctx->pool;
+    struct piece { dev_buf *buf; const void *src; size_t bytes, off; };
+    std::vector<piece> ups, wss;
+    size_t up_total = 256, ws_total = 0;                 // the transcript's word gather may read a few bytes in front of a record
+    auto add = [](std::vector<piece> &list, size_t &total, dev_buf &b, const void *src, size_t bytes) {
+        size_t sz = std::max<size_t>(bytes, 64);
+        list.push_back({&b, src, bytes, total});
+        total += (sz + 255) & ~(size_t)255;
+    };
+#define UP(buf, vec) add(ups, up_total, B->buf, (vec).data(), (vec).size() * sizeof((vec)[0]))
+    {
+        // the byte buffer comes straight from the caller's arrays; the gaps between its parts are zero
+        static const u8 zeros[128] = {0};
+        const size_t base = up_total;
+        add(ups, up_total, B->bytes, nullptr, hb.bytes_len);
+        auto part = [&](const void *src, size_t off, size_t bytes) { if (bytes) ups.push_back({nullptr, src, bytes, base + off}); };
+        part(records, 0, hb.rec_bytes);
+        part(zeros, hb.rec_bytes, hb.keys_base - hb.rec_bytes);
+        part(in->account_keys, hb.keys_base, 32 * in->n_accounts);
+        part(in->balance_cts, hb.cts_base, 64 * in->n_balances);
+        part(in->multisig_signers, hb.signers_base, 32 * hb.n_signer_keys);
+        part(zeros, hb.signers_base + 32 * hb.n_signer_keys, 64);
+    }
+    UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
     UP(tx_err0, hb.tx_err); UP(apply_err0, hb.apply_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
-    lap("uploads enqueued");
     u64 n_slots = hb.slot_of_used.size();
     u64 n_ops = hb.ops.size();
     u64 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (scan_blocks == 0) scan_blocks = 1;
     u64 n_parts = hb.cms.size() + hb.xfers.size() + hb.n_txs;
-#define RS(buf, bytes_) do { hipError_t e_ = B->buf.reserve(std::max<u64>((u64)(bytes_), 64)); if (e_ != hipSuccess) { set_error(ctx, std::string("alloc " #buf ": ") + hipGetErrorString(e_)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; } } while (0)
+#define RS(buf, bytes_) add(wss, ws_total, B->buf, nullptr, (size_t)(bytes_))
     RS(pts, 128ull * hb.n_points); RS(ok, hb.n_points); RS(chal, 32ull * hb.n_chal); RS(scalars, 32ull * hb.n_terms); RS(term_point, 4ull * hb.n_terms);
     RS(gh, 72ull * n_parts); RS(gh_sums, 72ull * 256); RS(rp_ctx, 36ull * RPC_SCALARS * hb.n_txs); RS(rp_acc, 72ull * hb.nm_cap);
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
@@ -399,14 +473,47 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
         RS(rp_mat, worst);
     }
 #undef RS
-    lap("workspace allocations");
+    auto fail = [&](const char *what, hipError_t e) { set_error(ctx, std::string(what) + ": " + hipGetErrorString(e)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; };
+    hipError_t he;
+    if ((he = B->arena_up.reserve(up_total + 256)) != hipSuccess) return fail("allocating the batch tables", he);
+    if ((he = B->arena_ws.reserve(ws_total + 256)) != hipSuccess) return fail("allocating the batch workspace", he);
+    for (auto &pc : ups) if (pc.buf) pc.buf->point_at(B->arena_up.p, pc.off, std::max<size_t>(pc.bytes, 64));
+    for (auto &pc : wss) pc.buf->point_at(B->arena_ws.p, pc.off, std::max<size_t>(pc.bytes, 64));
+    lap("device blocks");
+    {
+        const size_t want = std::min<size_t>(up_total, STAGE_MAX);
+        if (ctx->stage_cap < want) {
+            if (ctx->stage) (void)hipHostFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_cap = 0;
+            size_t cap = want + want / 4 + 4096;
+            if ((he = hipHostMalloc(&ctx->stage, cap, hipHostMallocDefault)) != hipSuccess) return fail("allocating pinned staging memory", he);
+            ctx->stage_cap = cap;
+        }
+        // slices of the concatenated layout: [lo, hi) in arena offsets
+        size_t lo = 0;
+        while (lo < up_total) {
+            size_t hi = std::min(up_total, lo + ctx->stage_cap);
+            for (auto &pc : ups) {
+                size_t a = std::max(pc.off, lo), b = std::min(pc.off + pc.bytes, hi);
+                if (a < b && pc.src) memcpy((char *)ctx->stage + (a - lo), (const char *)pc.src + (a - pc.off), b - a);
+            }
+            if ((he = hipMemcpyAsync((char *)B->arena_up.p + lo, ctx->stage, hi - lo, hipMemcpyHostToDevice, st)) != hipSuccess) return fail("uploading the batch tables", he);
+            if (hi < up_total && (he = hipStreamSynchronize(st)) != hipSuccess) return fail("uploading the batch tables", he);      // the staging memory is reused
+            lo = hi;
+        }
+    }
+    lap("tables staged and enqueued");
     // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
     HIPCHK(ctx, hipMemcpyAsync(B->pts.p, ctx->static_pts.p, 256 + 128ull * hb.nm_cap, hipMemcpyDeviceToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256 + 128ull * hb.nm_cap, ctx->static_pts.as<u8>() + 256 + 128ull * ctx->static_cap, 128ull * hb.nm_cap,
                                hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (wait_for_copies || up_total > ctx->stage_cap) HIPCHK(ctx, hipStreamSynchronize(st));
     lap("synchronize");
     return 0;
+}
+int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
+                         xhe_verdict *structural) {
+    return batch_upload_impl(ctx, records, offsets, n_txs, in, batch_out, structural, true);
 }
 
 int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t rng_seed[32]) {
@@ -488,7 +595,7 @@ int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
                          xhe_verdict *verdict, const uint8_t rng_seed[32]) {
     if (!ctx || !verdict || !rng_seed) return XHE_E_ARG;
     xhe_batch *B = nullptr;
-    int32_t rc = xhe_batch_upload(ctx, records, offsets, n_txs, in, &B, verdict);
+    int32_t rc = batch_upload_impl(ctx, records, offsets, n_txs, in, &B, verdict, false);
     if (rc) return rc;
     if (!verdict->accept) { xhe_batch_free(ctx, B); return 0; }
     rc = xhe_batch_verify(ctx, B, verdict, rng_seed);
