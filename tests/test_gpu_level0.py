@@ -108,3 +108,15 @@ def test_msm_rejects_bad_point(engine):
     import xelis_he_amd
     with pytest.raises(xelis_he_amd.XheError):
         engine.msm_vartime(le32(5) + le32(7), le32(1) + bytes(32))
+
+
+def test_wide_arithmetic_selftest():
+    """The one-point-per-wavefront arithmetic of the Horner stage (xhe_wide.h) against the one-point-per-lane arithmetic, on
+    the device: products at the magnitude limits, record loads, a chain of doublings and additions (tools/test_wide.hip,
+    built by __graft_entry__.build())."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "test_wide")
+    if not os.path.exists(exe):
+        pytest.skip("tools/test_wide is not built (__graft_entry__.build() builds it)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "PASS" in r.stdout, (r.returncode, r.stdout, r.stderr)

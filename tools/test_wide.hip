@@ -66,7 +66,7 @@ int main() {
     if (hipMalloc(&d_out, 8) != hipSuccess || hipMalloc(&d_scr, 256) != hipSuccess) { printf("no device\n"); return 2; }
     hipLaunchKernelGGL(k_test, dim3(1), dim3(64), 0, 0, d_out, d_scr);
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 2; }
-    hipMemcpy(h, d_out, 8, hipMemcpyDeviceToHost);
+    if (hipMemcpy(h, d_out, 8, hipMemcpyDeviceToHost) != hipSuccess) { printf("read-back failed\n"); return 2; }
     if (h[0]) { printf("FAIL: %u mismatches, first case %u\n", h[0], h[1]); return 1; }
     printf("PASS\n");
     return 0;
