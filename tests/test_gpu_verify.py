@@ -404,3 +404,25 @@ def test_transcript_stream_in_several_passes(engine, oracle, monkeypatch):
     g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
     r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
     assert g == r and g[0] == 0 and g[2] == 280
+
+
+def test_large_batch_schedule_on_a_small_batch(engine, oracle, monkeypatch):
+    """Batches of 32768 transactions or more take another schedule (public keys decoded and signatures verified on a stream
+    of their own from the start).  XHE_SIG_STREAM_MIN_TXS = 1 runs it on the 256-transaction mixed batch (1.25 signatures
+    per transaction, co-signatures included): same verdicts, ledger and failing indices."""
+    sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)
+    ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb)
+    monkeypatch.setenv("XHE_SIG_STREAM_MIN_TXS", "1")
+    got, cts, ms = _raw_verify(engine.lib, engine, engine.ctx, sb)
+    assert got == ref == (1, codes.OK, -1)
+    assert cts == ref_cts and ms == ref_ms
+    offs = list(sb.offsets)
+    # the main signature's s and e of a transfer, a co-signature, the signature of the last transaction
+    for tx, back in [(16 * 2 + 3, 10), (16 * 2 + 3, 40), (16 * 3 + 14, 64 + 65 + 10), (255, 1)]:
+        bad = bytearray(sb.records)
+        bad[offs[tx + 1] - back] ^= 1
+        g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
+        r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
+        assert g == r and g[0] == 0 and g[2] == tx, (tx, back, g, r)
+    sb2 = SyntheticBatch(700, n_transfers=1, n_senders=50, seed=b"lane-700")
+    assert _raw_verify(engine.lib, engine, engine.ctx, sb2) == _raw_verify(None, oracle, None, sb2)

@@ -144,7 +144,9 @@ struct stage_timer {
 };
 
 static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory per context, at most
-static constexpr u32 SIG_STREAM_MIN_TXS = 32768;     // from this batch size on the signatures get a stream of their own
+// From this batch size on a verification is bound by total work rather than by its chain of kernels and the signatures get a
+// stream of their own.  XHE_SIG_STREAM_MIN_TXS overrides it (the tests run the large-batch schedule on small batches).
+static u32 sig_stream_min_txs() { const char *e = getenv("XHE_SIG_STREAM_MIN_TXS"); return e ? (u32)strtoul(e, nullptr, 10) : 32768u; }
 
 struct msm_workspace { dev_buf hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
 
@@ -672,7 +674,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     // side 1: the bulk of the points, then the signatures.  Small batches are chains of short kernels and every stream beyond
     // three may share a hardware queue with the caller's; large batches are bound by total work and gain more from the
     // signatures starting at once on a stream of their own (side 2, with the public keys decoded there).
-    const bool own_sig_stream = n_txs >= SIG_STREAM_MIN_TXS;
+    const bool own_sig_stream = n_txs >= sig_stream_min_txs();
     hipStream_t ssig = own_sig_stream ? ctx->side[2] : s1;
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
     if (own_sig_stream) {
