@@ -407,7 +407,7 @@ def test_transcript_stream_in_several_passes(engine, oracle, monkeypatch):
 
 
 def test_large_batch_schedule_on_a_small_batch(engine, oracle, monkeypatch):
-    """Batches of 32768 transactions or more take another schedule (public keys decoded and signatures verified on a stream
+    """Batches of 2048 transactions or more take another schedule (public keys decoded and signatures verified on a stream
     of their own from the start).  XHE_SIG_STREAM_MIN_TXS = 1 runs it on the 256-transaction mixed batch (1.25 signatures
     per transaction, co-signatures included): same verdicts, ledger and failing indices."""
     sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)

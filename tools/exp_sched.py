@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stage times of one synthetic batch (generated once, verified several times), optionally under variants of the library
-selected through the environment: variant bit 0 = one-pass multiscalar sort (XHE_MSM_ONEPASS).
+selected through the environment: variant bit 0 = one-pass multiscalar sort (XHE_MSM_ONEPASS), bit 1 = signatures behind the bulk
+decode on its stream instead of a stream of their own (XHE_SIG_STREAM_MIN_TXS=4294967295).
 usage: tools/exp_sched.py <txs> <transfers> <variant values...>"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +21,12 @@ for e in exps:
         os.environ["XHE_MSM_ONEPASS"] = "1"
     else:
         os.environ.pop("XHE_MSM_ONEPASS", None)
+    if e & 2:
+        os.environ["XHE_SIG_STREAM_MIN_TXS"] = "4294967295"
+    else:
+        os.environ.pop("XHE_SIG_STREAM_MIN_TXS", None)
     acc = {}
-    reps = 6
+    reps = 10
     t0 = None
     for i in range(reps + 2):
         if i == 2: t0 = time.perf_counter()

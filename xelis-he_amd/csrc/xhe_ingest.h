@@ -43,6 +43,7 @@ struct host_batch {
     std::vector<dev_dec> decs;             // decode list; point index = n_static + position
     std::vector<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
     std::vector<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
+    std::vector<u32> bulk_decs;            // positions in decs[] of every other point
     std::vector<dev_op> ops;               // sorted by slot
     std::vector<dev_sig> sigs;
     std::vector<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
@@ -122,6 +123,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     auto new_point = [&](u64 off, u32 rp_tx, u32 early = 0) -> u32 {          // early: 1 = ledger scan input, 2 = key
         if (early == 1) hb.early_decs.push_back((u32)hb.decs.size());
         if (early == 2) hb.key_decs.push_back((u32)hb.decs.size());
+        if (early == 0) hb.bulk_decs.push_back((u32)hb.decs.size());
         hb.decs.push_back({off, early, 0u}); hb.rp_dec_tx.push_back(rp_tx);
         return hb.n_static + (u32)hb.decs.size() - 1;
     };
@@ -156,7 +158,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             n_xf += T; n_cm += A; n_ms += recs[i].n_multisig; n_pts += 4 + 2ull * recs[i].lg() + 6 * T + 4 * A + 1;
         }
         n_pts += 2 * n_xf + 2 * n_cm;                  // ledger ciphertexts touched for the first time, receiver keys
-        hb.decs.reserve(n_pts); hb.rp_dec_tx.reserve(n_pts); hb.early_decs.reserve(5 * n_xf + 2 * n_cm); hb.key_decs.reserve(n + n_xf);
+        hb.decs.reserve(n_pts); hb.rp_dec_tx.reserve(n_pts); hb.early_decs.reserve(5 * n_xf + 2 * n_cm); hb.key_decs.reserve(n + n_xf); hb.bulk_decs.reserve(n_pts);
         hb.cms.reserve(n_cm); hb.xfers.reserve(n_xf); hb.sigs.reserve(n + n_ms); hb.segs.reserve(2 * n + n_cm + 2 * n_xf);
     }
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_of;

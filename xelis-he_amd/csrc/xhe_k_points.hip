@@ -82,15 +82,12 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 
 // ---- decode ----------------------------------------------------------------------------------------
 static constexpr u32 DECODE_MAX_BLOCKS = 512;
-// list != null: a pass over the n listed entries (the points the ledger scan waits for, or the public keys);
-// list == null: all n entries except those whose mark (0 bulk, 1 ledger scan input, 2 public key) is set in skip_mask
+// A pass over the n listed entries of decs[] (the points the ledger scan waits for, the public keys, or all the others).
 __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
-                                                        u32 *__restrict__ pts, u8 *__restrict__ ok, u32 skip_mask) {
-    if (list) wave_priority_high(); else wave_priority_mid();      // listed points head the ledger scan and the signatures; the bulk only has to beat the accumulation
+                                                        u32 *__restrict__ pts, u8 *__restrict__ ok, u32 background) {
+    if (background) wave_priority_mid(); else wave_priority_high();   // the first two head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
-        u32 i = g;
-        if (list) i = list[g];
-        else if ((skip_mask >> decs[g].early) & 1) continue;
+        u32 i = list[g];
         u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);
         ge p; bool good = ristretto_decode_words(p, w);
         ge_niels_store(pts + 32ull * (pt_base + i), ge_to_niels_affine(p));
@@ -176,11 +173,11 @@ void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pt
 void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab) {
     if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
-void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool bulk_takes_keys) {
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background) {
     // at most two wavefronts per SIMD (512 workgroups of four on 256 CUs): the decode is the widest kernel of a verification and
     // runs beside the critical path, whose few long-running wavefronts must find free slots the moment they are launched
     u32 blocks = grid_for(n, 256);
-    if (n) hipLaunchKernelGGL(k_decode_list, dim3(blocks < DECODE_MAX_BLOCKS ? blocks : DECODE_MAX_BLOCKS), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok, bulk_takes_keys ? 2u : 6u);
+    if (n) hipLaunchKernelGGL(k_decode_list, dim3(blocks < DECODE_MAX_BLOCKS ? blocks : DECODE_MAX_BLOCKS), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok, background ? 1u : 0u);
 }
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
