@@ -44,6 +44,21 @@ def measured_traffic(txs, transfers):
     return int(total) if found == 2 else None
 
 
+def measured_valu_instructions(txs, transfers):
+    """Wave-level VALU instructions per launch of the dominant kernel (SQ_INSTS_VALU) from the committed rocprofv3 --pmc
+    pass of this very workload; None when no matching summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_%dtx.csv" % txs)))
+    if not files or transfers != 1:
+        return None
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].endswith("k_msm_accumulate") and row["counter"] == "SQ_INSTS_VALU":
+                return float(row["avg"])
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +192,18 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                     "traffic": measured_traffic(args.txs, args.transfers), "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": algo_bytes}
 
+    # The kernel is bound by VALU issue, not by HBM: wave-instructions per launch (PMC) / launch time against one
+    # wave-instruction per 4 cycles per SIMD (a 64-wide wavefront on a 16-lane SIMD), the chip's upper bound for 32-bit VALU work.
+    valu = None
+    n_valu = measured_valu_instructions(args.txs, args.transfers) if not mixed else None
+    if n_valu and acc_ms > 0:
+        prop = torch.cuda.get_device_properties(local_rank)
+        clock_hz = getattr(prop, "clock_rate", 2400000) * 1e3
+        peak = prop.multi_processor_count * 4 * clock_hz / 4.0
+        rate = n_valu / (acc_ms * 1e-3)
+        valu = {"kernel": "k_msm_accumulate", "wave_instructions": int(n_valu), "achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2),
+                "unit": "G wave-instructions/s", "frac": round(rate / peak, 4), "simds": prop.multi_processor_count * 4, "clock_mhz": round(clock_hz / 1e6)}
+
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -201,7 +228,7 @@ def main():
             "config": {"workload": ("%d-tx mixed batch per GPU (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers), %d account groups" % (args.txs, args.txs // 16)) if mixed
                        else "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
                        "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stage_detail_ms": {k: round(v, 4) for k, v in detail.items()},
             "setup": {"generate_s": round(gen_s, 2), "parse_upload_s": round(upload_s, 4)},

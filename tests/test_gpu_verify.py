@@ -426,3 +426,22 @@ def test_large_batch_schedule_on_a_small_batch(engine, oracle, monkeypatch):
         assert g == r and g[0] == 0 and g[2] == tx, (tx, back, g, r)
     sb2 = SyntheticBatch(700, n_transfers=1, n_senders=50, seed=b"lane-700")
     assert _raw_verify(engine.lib, engine, engine.ctx, sb2) == _raw_verify(None, oracle, None, sb2)
+
+
+def test_transcripts_on_one_lane_per_transaction(engine, oracle, monkeypatch):
+    """Passes of more than 2048 wavefronts hash the transcripts with one lane per transaction instead of a pair of lanes
+    (bit-interleaved state).  XHE_TRANSCRIPT_PAIR_MAX_WAVES = 0 runs that kernel on small batches (five transcript shapes of
+    the mixed batch, eight-transfer transactions): same verdicts, ledger and failing index as the oracle."""
+    monkeypatch.setenv("XHE_TRANSCRIPT_PAIR_MAX_WAVES", "0")
+    sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)
+    ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb)
+    got, cts, ms = _raw_verify(engine.lib, engine, engine.ctx, sb)
+    assert got == ref == (1, codes.OK, -1)
+    assert cts == ref_cts and ms == ref_ms
+    sb8 = SyntheticBatch(40, n_transfers=8, n_senders=8, seed=b"one-lane-t8")
+    assert _raw_verify(engine.lib, engine, engine.ctx, sb8) == _raw_verify(None, oracle, None, sb8)
+    bad = bytearray(sb8.records)
+    bad[list(sb8.offsets)[33] + 16 + 4 + 49 + 100] ^= 1
+    g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb8, bytes(bad))
+    r, _, _ = _raw_verify(None, oracle, None, sb8, bytes(bad))
+    assert g == r and g[0] == 0 and g[2] == 33

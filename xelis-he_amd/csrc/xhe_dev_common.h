@@ -65,6 +65,9 @@ __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setpri
 // the point decoding and the static-generator scalars: the multiscalar check waits for them, the signatures (default
 // priority) have slack until the verdict
 __device__ __forceinline__ void wave_priority_mid() { __builtin_amdgcn_s_setprio(1); }
+// the decodes that head the ledger scan and the signatures: ahead of the bulk, but behind the hash chains of the transcripts
+// that start at the same moment (at equal priority the two share the SIMDs and the chain takes twice as long)
+__device__ __forceinline__ void wave_priority_upper() { __builtin_amdgcn_s_setprio(2); }
 
 // 64-bit rotate left by a constant on a (lo, hi) pair of 32-bit halves: two v_alignbit_b32
 template <int N>
@@ -138,6 +141,96 @@ __device__ __forceinline__ void keccak_f1600_regs(u64 (&a)[25]) {
     for (int round = 0; round < 24; round++) keccak_round_halves(al, ah, (u32)RC[round], (u32)(RC[round] >> 32));
 #pragma unroll
     for (int i = 0; i < 25; i++) a[i] = (u64)al[i] | ((u64)ah[i] << 32);
+}
+
+// ---- Keccak-f[1600] on a pair of lanes ----------------------------------------------------------------------------
+// Bit-interleaved state: the even lane of a pair holds the even-numbered bits of the 25 words, the odd lane the odd-numbered
+// ones (25 registers each).  theta, chi and iota are bitwise and stay inside a lane; a 64-bit rotation by 2k is a 32-bit
+// rotation by k of both halves, one by 2k+1 takes the partner's half (one DPP move) and rotates it by k+1 (even lane) or k
+// (odd lane).  A lane issues ~110 instructions per round instead of ~195 for the whole state, which is what counts for a
+// hash chain that is bound by the issue rate of one wavefront.
+// even bits of a 64-bit word -> low 32 bits, odd bits -> high 32 bits
+__host__ __device__ constexpr u32 bit_unzip32(u32 x) {
+    u32 t = (x ^ (x >> 1)) & 0x22222222u; x ^= t ^ (t << 1);
+    t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x ^= t ^ (t << 2);
+    t = (x ^ (x >> 4)) & 0x00f000f0u; x ^= t ^ (t << 4);
+    t = (x ^ (x >> 8)) & 0x0000ff00u; x ^= t ^ (t << 8);
+    return x;                                          // even bits in the low half, odd bits in the high half
+}
+__host__ __device__ constexpr u32 bit_zip32(u32 x) {
+    u32 t = (x ^ (x >> 8)) & 0x0000ff00u; x ^= t ^ (t << 8);
+    t = (x ^ (x >> 4)) & 0x00f000f0u; x ^= t ^ (t << 4);
+    t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x ^= t ^ (t << 2);
+    t = (x ^ (x >> 1)) & 0x22222222u; x ^= t ^ (t << 1);
+    return x;
+}
+__host__ __device__ constexpr u64 bit_unzip64(u64 v) {
+    u32 lo = bit_unzip32((u32)v), hi = bit_unzip32((u32)(v >> 32));
+    u32 even = (lo & 0xffffu) | (hi << 16), odd = (lo >> 16) | (hi & 0xffff0000u);
+    return (u64)even | ((u64)odd << 32);
+}
+__host__ __device__ constexpr u64 bit_zip64(u32 even, u32 odd) {
+    u32 lo = bit_zip32((even & 0xffffu) | (odd << 16)), hi = bit_zip32((even >> 16) | (odd & 0xffff0000u));
+    return (u64)lo | ((u64)hi << 32);
+}
+// the partner lane's value (lanes 2t and 2t+1 form a pair)
+__device__ __forceinline__ u32 pair_swap(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm 1,0,3,2 */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 rotl32v(u32 x, u32 neg_count /* (32 - k) & 31 */) { return __builtin_amdgcn_alignbit(x, x, neg_count); }
+// rotation counts of rho in the order of XHE_KECCAK2_RHO_PI below; odd counts 2k+1 carry their k in a per-lane register
+struct keccak_pair_consts { u32 one; u32 k[12]; };     // (32 - (k + is_even_lane)) & 31 for theta's rotation by 1 and the 12 odd rho counts
+__device__ __forceinline__ keccak_pair_consts keccak_pair_setup(u32 odd_lane) {
+    constexpr int odd_counts[12] = {1, 27, 55, 3, 43, 25, 39, 41, 45, 15, 21, 61};
+    keccak_pair_consts c;
+    c.one = (32u - (0u + (odd_lane ^ 1u))) & 31u;
+#pragma unroll
+    for (int i = 0; i < 12; i++) c.k[i] = (32u - ((u32)(odd_counts[i] >> 1) + (odd_lane ^ 1u))) & 31u;
+    return c;
+}
+#define XHE_K2_EVEN(DST, SRC, N) b[DST] = __builtin_amdgcn_alignbit(s[SRC], s[SRC], (32 - (N) / 2) & 31)
+#define XHE_K2_ODD(DST, SRC, IDX) b[DST] = rotl32v(pair_swap(s[SRC]), kc.k[IDX])
+__device__ __forceinline__ void keccak_round_pair(u32 (&s)[25], const keccak_pair_consts &kc, u32 rc_half) {
+    u32 c[5], r[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = xor3(xor3(s[x], s[x + 5], s[x + 10]), s[x + 15], s[x + 20]);
+#pragma unroll
+    for (int x = 0; x < 5; x++) r[x] = rotl32v(pair_swap(c[x]), kc.one);          // this lane's half of rotl64(C[x], 1)
+#pragma unroll
+    for (int i = 0; i < 25; i++) s[i] = xor3(s[i], c[(i % 5 + 4) % 5], r[(i % 5 + 1) % 5]);
+    u32 b[25];
+    b[0] = s[0];
+    XHE_K2_ODD(10, 1, 0);    XHE_K2_EVEN(20, 2, 62);  XHE_K2_EVEN(5, 3, 28);   XHE_K2_ODD(15, 4, 1);
+    XHE_K2_EVEN(16, 5, 36);  XHE_K2_EVEN(1, 6, 44);   XHE_K2_EVEN(11, 7, 6);   XHE_K2_ODD(21, 8, 2);
+    XHE_K2_EVEN(6, 9, 20);   XHE_K2_ODD(7, 10, 3);    XHE_K2_EVEN(17, 11, 10); XHE_K2_ODD(2, 12, 4);
+    XHE_K2_ODD(12, 13, 5);   XHE_K2_ODD(22, 14, 6);   XHE_K2_ODD(23, 15, 7);   XHE_K2_ODD(8, 16, 8);
+    XHE_K2_ODD(18, 17, 9);   XHE_K2_ODD(3, 18, 10);   XHE_K2_EVEN(13, 19, 8);  XHE_K2_EVEN(14, 20, 18);
+    XHE_K2_EVEN(24, 21, 2);  XHE_K2_ODD(9, 22, 11);   XHE_K2_EVEN(19, 23, 56); XHE_K2_EVEN(4, 24, 14);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5) {
+#pragma unroll
+        for (int x = 0; x < 5; x++) s[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+    }
+    s[0] ^= rc_half;
+}
+#undef XHE_K2_EVEN
+#undef XHE_K2_ODD
+struct keccak_rc_halves { u32 even[24], odd[24]; };
+__host__ __device__ constexpr keccak_rc_halves keccak_rc_unzipped() {
+    const u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    keccak_rc_halves h{};
+    for (int i = 0; i < 24; i++) { u64 z = bit_unzip64(RC[i]); h.even[i] = (u32)z; h.odd[i] = (u32)(z >> 32); }
+    return h;
+}
+// Keccak-f[1600] on this lane's half of the bit-interleaved state
+__device__ __forceinline__ void keccak_f1600_pair(u32 (&s)[25], const keccak_pair_consts &kc, u32 odd_lane) {
+    constexpr keccak_rc_halves RC = keccak_rc_unzipped();
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) keccak_round_pair(s, kc, odd_lane ? RC.odd[round] : RC.even[round]);
 }
 
 // Batch factors: scalar(s) = wide-reduce(Keccak-f[1600](seed || index || domain || SHAKE padding)) -- one permutation

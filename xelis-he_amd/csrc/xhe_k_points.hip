@@ -85,7 +85,7 @@ static constexpr u32 DECODE_MAX_BLOCKS = 512;
 // A pass over the n listed entries of decs[] (the points the ledger scan waits for, the public keys, or all the others).
 __global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
                                                         u32 *__restrict__ pts, u8 *__restrict__ ok, u32 background) {
-    if (background) wave_priority_mid(); else wave_priority_high();   // the first two head the ledger scan and the signatures; the bulk only has to beat the accumulation
+    if (background) wave_priority_mid(); else wave_priority_upper();  // the first two head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         u32 i = list[g];
         u32 w[8]; load_words_unaligned(w, bytes + decs[i].off);

@@ -112,6 +112,8 @@ __global__ void __launch_bounds__(64) k_transcript_serial(const u8 *__restrict__
 // Transactions are taken from a list sorted by template and padded per template to whole tiles, so a
 // wavefront runs one template and its control flow is uniform.
 static constexpr u32 TR_PAD = 0xffffffffu;
+// XHE_TRANSCRIPT_PAIR_MAX_WAVES: largest pass (in wavefronts of the pair kernel) that still runs on lane pairs; 0 = never
+static u64 transcript_pair_max_waves() { const char *e = getenv("XHE_TRANSCRIPT_PAIR_MAX_WAVES"); return e ? strtoull(e, nullptr, 10) : 2048ull; }
 static constexpr u32 STAGE_ROWS = 7;         // words of a block handled per pass of a 448-thread workgroup
 
 // the eight bytes of state word l (< 21) of block b through its word descriptor (transcript_word)
@@ -124,7 +126,7 @@ __device__ __forceinline__ u64 transcript_gather(const u32 *__restrict__ desc, u
 
 __global__ void __launch_bounds__(64 * STAGE_ROWS) k_transcript_stage(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl,
                                                                       const u32 *__restrict__ segs, const u32 *__restrict__ list, const transcript_tile *__restrict__ tiles,
-                                                                      u32 tile0, u64 *__restrict__ stream, u32 *__restrict__ tx_err, u32 *__restrict__ rp_err) {
+                                                                      u32 tile0, u64 *__restrict__ stream, u32 *__restrict__ tx_err, u32 *__restrict__ rp_err, u32 unzip) {
     wave_priority_high();
     const u32 tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, row = threadIdx.x >> 6;
     const transcript_tile tt = tiles[tile];
@@ -149,7 +151,10 @@ __global__ void __launch_bounds__(64 * STAGE_ROWS) k_transcript_stage(const u8 *
     u64 *out = stream + tt.stream_off + lane;
     for (u32 b = blockIdx.y; b < n_blocks; b += gridDim.y) {
 #pragma unroll
-        for (u32 w = row; w < 21; w += STAGE_ROWS) out[(u64)(b * 21 + w) * 64] = transcript_gather(desc, b, w, rec, seg);
+        for (u32 w = row; w < 21; w += STAGE_ROWS) {
+            u64 v = transcript_gather(desc, b, w, rec, seg);
+            out[(u64)(b * 21 + w) * 64] = unzip ? bit_unzip64(v) : v;         // for k_transcript_keccak_pair: even bits | odd bits
+        }
     }
 }
 
@@ -189,6 +194,51 @@ __global__ void __launch_bounds__(64) k_transcript_keccak(const dev_tx *__restri
     }
 }
 
+// The same on a pair of lanes per transaction (bit-interleaved state, keccak_f1600_pair): a workgroup of two wavefronts per
+// tile, lane pair t of the workgroup runs transaction t of the tile.  Reads the stream k_transcript_stage wrote with
+// unzip = 1 (word = even bits | odd bits << 32): lane 2t takes the low, lane 2t+1 the high 32 bits.
+__global__ void __launch_bounds__(128) k_transcript_keccak_pair(const dev_tx *__restrict__ txs, const u32 *__restrict__ tmpl, const u32 *__restrict__ list,
+                                                               const transcript_tile *__restrict__ tiles, u32 tile0, const u64 *__restrict__ stream, u32 *__restrict__ chal) {
+    wave_priority_high();
+    const u32 tile = tile0 + blockIdx.x, t = threadIdx.x >> 1, odd = threadIdx.x & 1;
+    const u32 tmpl_off = __builtin_amdgcn_readfirstlane(tiles[tile].tmpl_off);
+    const u64 stream_off = tiles[tile].stream_off;
+    const u32 i = list[64ull * tile + t];
+    if (i == TR_PAD) return;
+    const u32 chal_off = txs[i].chal_off;
+    const u32 *hdr = tmpl + tmpl_off;
+    const u32 n_blocks = __builtin_amdgcn_readfirstlane(hdr[TT_H_BLOCKS]);
+    const u32 *chal_after = hdr + TT_H_WORDS;
+    const u32 *in = (const u32 *)(stream + stream_off) + threadIdx.x;
+    const keccak_pair_consts kc = keccak_pair_setup(odd);
+    u32 s[25], nx[21];
+#pragma unroll
+    for (int w = 0; w < 25; w++) s[w] = 0;
+#pragma unroll
+    for (int w = 0; w < 21; w++) nx[w] = in[128 * w];
+    for (u32 b = 0; b < n_blocks; b++) {
+#pragma unroll
+        for (int w = 0; w < 21; w++) s[w] ^= nx[w];
+        if (b + 1 < n_blocks) {                        // in flight during the permutation
+#pragma unroll
+            for (int w = 0; w < 21; w++) nx[w] = in[(u64)((b + 1) * 21 + w) * 128];
+        }
+        keccak_f1600_pair(s, kc, odd);
+        u32 ci = __builtin_amdgcn_readfirstlane(chal_after[b]);
+        if (ci != TT_NONE) {
+            // both lanes rebuild the 64 bytes; the even lane reduces and stores
+            u32 w[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                u32 other = pair_swap(s[k]);
+                u64 v = bit_zip64(odd ? other : s[k], odd ? s[k] : other);
+                w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); s[k] = 0;
+            }
+            if (!odd) store_scalar_words(chal + 8ull * (chal_off + ci), sc_from_wide_words(w));
+        }
+    }
+}
+
 
 // ---- signatures ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_blake3_preimages(const u8 *__restrict__ bytes, const dev_tx *__restrict__ txs, const u32 *__restrict__ hash_tx, u32 n,
@@ -207,8 +257,14 @@ void launch_transcript(hipStream_t st, const u8 *bytes, const dev_tx *txs, const
                        u32 *tx_err, u32 *rp_err) {
     for (const transcript_pass &ps : plan.passes) {
         u32 gy = ps.max_blocks < 64 ? ps.max_blocks : 64;
-        hipLaunchKernelGGL(k_transcript_stage, dim3(ps.n_tiles, gy ? gy : 1), dim3(64 * STAGE_ROWS), 0, st, bytes, txs, tmpl, segs, list, tiles, ps.tile0, stream, tx_err, rp_err);
-        hipLaunchKernelGGL(k_transcript_keccak, dim3(ps.n_tiles), dim3(64), 0, st, txs, tmpl, list, tiles, ps.tile0, stream, chal);
+        // A pair of lanes per transaction while the wavefronts of a pass still find a SIMD each (the chain of permutations is
+        // bound by one wavefront's issue rate and a lane of a pair issues ~45 % fewer instructions); one lane per transaction
+        // beyond that, where the total instruction count decides (it is ~10 % higher for the pairs).
+        const bool pairs = 2ull * ps.n_tiles <= transcript_pair_max_waves();
+        hipLaunchKernelGGL(k_transcript_stage, dim3(ps.n_tiles, gy ? gy : 1), dim3(64 * STAGE_ROWS), 0, st, bytes, txs, tmpl, segs, list, tiles, ps.tile0, stream, tx_err, rp_err,
+                           pairs ? 1u : 0u);
+        if (pairs) hipLaunchKernelGGL(k_transcript_keccak_pair, dim3(ps.n_tiles), dim3(128), 0, st, txs, tmpl, list, tiles, ps.tile0, stream, chal);
+        else hipLaunchKernelGGL(k_transcript_keccak, dim3(ps.n_tiles), dim3(64), 0, st, txs, tmpl, list, tiles, ps.tile0, stream, chal);
     }
     if (n_serial) hipLaunchKernelGGL(k_transcript_serial, dim3(grid_for(n_serial, 64)), dim3(64), 0, st, bytes, txs, cms, xfers, serial_list, n_serial, chal, tx_err, rp_err);
 }

@@ -622,6 +622,12 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     const u32 n_parts = n_cm + n_xf + n_txs;
     stage_timer &tm = ctx->timer;
     tm.begin();
+    // XHE_ENQUEUE_TIMES=1: host clock at the points of the launch sequence (how far ahead of the device the enqueueing runs)
+    static const bool host_times = getenv("XHE_ENQUEUE_TIMES") != nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
+    auto host_mark = [&](const char *what) {
+        if (host_times) fprintf(stderr, "[xhe enqueue] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
+    };
     HIPCHK(ctx, tm.mark("setup", st));
     {
         setup_jobs jobs;
@@ -698,6 +704,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, tm.close("signatures", ssig));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], ssig));
     if (int32_t rc = enqueue_scan()) return rc;
+    host_mark("side streams enqueued");
     // main: proof scalars (sigma terms, range-proof terms, per-transaction range-proof context)
     HIPCHK(ctx, tm.mark("proof_scalars", st));
     {
@@ -735,12 +742,14 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
     HIPCHK(ctx, hipGetLastError());
+    host_mark("static chain enqueued");
     // merged multiscalar check: sigma terms + range-proof terms (+ static generators, unless their sum comes from the tables)
     msm_deps deps;
     deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[2];
     if (use_tables) { deps.extra_point = ctx->static_sum.as<u32>(); deps.extra_ready = ctx->ev_static_done; }
     int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps);
     if (rc) return rc;
+    host_mark("multiscalar check enqueued");
     HIPCHK(ctx, tm.mark("join_signatures", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_points_checked, 0));
@@ -749,7 +758,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, tm.mark("end", st));
     u32 host[16];
     HIPCHK(ctx, hipMemcpyAsync(host, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
+    host_mark("all enqueued");
     HIPCHK(ctx, hipStreamSynchronize(st));
+    host_mark("synchronised");
     tm.finish();
     u64 first_err = (u64)host[0] | ((u64)host[1] << 32);
     u32 first_rp = host[2], merged_identity = host[12];
