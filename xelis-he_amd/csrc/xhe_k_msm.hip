@@ -52,16 +52,22 @@ msm_plan msm_make_plan(u64 n) {
     if (M < 32 && entries >= (1u << 20)) M = 32;
     // Every thread takes one chunk, and a chunk is ~M * 2000 instructions: when the chunks need a little more than a whole
     // number of rounds of the chip's thread slots (256 CUs x 3 workgroups of 256 at this kernel's register count), the few
-    // workgroups of the last round run alone at a lone wave's rate - a third of the kernel's time at the bench size.  So the
-    // chunk grows until the chunks fit the rounds they need with a few per cent to spare.
+    // workgroups of the last round run alone at a lone wave's rate - a third of the kernel's time at the bench size.  The
+    // kernel's time goes as rounds * M, so among M/2..2M the chunk length with the smallest product is taken, counting the
+    // rounds with a few per cent of the slots to spare; of equal products the shorter chunk wins (more, shorter rounds: inside
+    // a verification the signature kernel holds part of the slots and the rounds are not the stand-alone ones; measured on the
+    // 10 000-transaction batch: M = 32 -> 0.48-0.53 ms, 34 (one round) -> 0.51 ms, 17 (two rounds) -> 0.43-0.45 ms, 12 -> 0.42 ms
+    // with the merge up from 0.035 to 0.066 ms).  XHE_MSM_CHUNK overrides the choice.
     {
-        const u64 slots = 256ull * 3 * 256;
-        u64 chunks = entries / M + 1, rounds = (chunks + slots - 1) / slots;
-        if (rounds <= 8) {
-            u64 fit = (entries + rounds * (slots - slots / 32) - 1) / (rounds * (slots - slots / 32));
-            if (fit > M && fit <= 2ull * M) M = (u32)fit;
+        const u64 slots = 256ull * 3 * 256, usable = slots - slots / 32;
+        u64 best_cost = ~0ull; u32 best = M;
+        for (u32 m = (M / 2 > 8 ? M / 2 : 8); m <= 2 * M; m++) {
+            u64 chunks = entries / m + 1, rounds = (chunks + usable - 1) / usable;
+            if (rounds > 8) continue;
+            if (rounds * m < best_cost) { best_cost = rounds * m; best = m; }
         }
-        p.M = M;
+        p.M = best;
+        if (const char *e = getenv("XHE_MSM_CHUNK")) { u32 v = (u32)strtoul(e, nullptr, 10); if (v >= 1 && v <= 1024) p.M = v; }
     }
     // terms per workgroup of the counting sort: every workgroup reads and writes all B counters of its window, so a tile
     // holds at least two terms per bucket once there are enough tiles (tiles * W workgroups) to cover the chip
