@@ -62,8 +62,8 @@ def measured_valu_instructions(txs, transfers):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--txs", type=int, default=10000, help="transactions per GPU batch")
     ap.add_argument("--transfers", type=int, default=1)
     ap.add_argument("--workload", choices=["transfers", "mixed"], default="transfers",
