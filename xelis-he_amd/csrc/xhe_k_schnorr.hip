@@ -100,15 +100,15 @@ __device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, u32 (*ta
     {
         ge_niels pn = ge_niels_load(pts + 32ull * sg.key_pt);
         qd_point P = qd_from_ge(ge_from_niels_affine(pn), role);
-        qd_point m[9];
-        m[0] = qd_identity(role); m[1] = P;
-        m[2] = qd_double(P, role); m[3] = qd_add(m[2], P, role); m[4] = qd_double(m[2], role); m[5] = qd_add(m[4], P, role);
-        m[6] = qd_double(m[3], role); m[7] = qd_add(m[6], P, role); m[8] = qd_double(m[4], role);
-#pragma unroll
+        // multiples 0..8 of P, each written to the table as soon as it exists (one running point instead of nine live ones
+        // keeps the kernel's register count low enough to share a SIMD with two decode wavefronts)
+        qd_point cur = qd_identity(role);
+#pragma unroll 1
         for (int k = 0; k < 9; k++) {
-            fe c = qd_to_cached(m[k], role);
+            fe c = qd_to_cached(cur, role);
 #pragma unroll
             for (int l = 0; l < 10; l++) tab[k][l][lane] = c.v[l];
+            cur = qd_add(cur, P, role);
         }
     }
     // Q = e * P with signed radix-16 digits in [-8, 8], most significant first.  The carry into digit k depends on
