@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scal
         digits[(u64)w * n + i] = (unsigned short)(a | (d < 0 ? 0x8000u : 0u));
     });
 }
+static constexpr u32 SORT_UNROLL = 8;        // independent loads in flight per thread in the counting and scattering loops
 // workgroup (tile, window): counts of the tile's digits per bucket -> tile_hist[(w * tiles + tile) * B + b]
 __global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, u32 *__restrict__ tile_hist) {
     wave_priority_high();
@@ -157,9 +158,14 @@ __global__ void __launch_bounds__(512) k_msm_tile_hist(const unsigned short *__r
     for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
-    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        u32 a = digits[(u64)w * n + k] & 0x7fffu;
-        if (a) atomicAdd(&cnt[a - 1], 1u);
+    // the loads of SORT_UNROLL iterations are issued together: one at a time, every iteration waits a full memory latency
+    const unsigned short *dg = digits + (u64)w * n;
+    for (u64 k0 = lo + threadIdx.x; k0 < hi; k0 += (u64)SORT_UNROLL * blockDim.x) {
+        u32 a[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u64 k = k0 + (u64)j * blockDim.x; a[j] = k < hi ? (dg[k] & 0x7fffu) : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) if (a[j]) atomicAdd(&cnt[a[j] - 1], 1u);
     }
     __syncthreads();
     u32 *out = tile_hist + ((u64)w * tiles + tile) * p.B;
@@ -172,11 +178,12 @@ __global__ void __launch_bounds__(256) k_msm_tile_prefix(u32 *__restrict__ tile_
     if (g >= p.W * p.B) return;
     u32 w = g / p.B, b = g % p.B;
     u32 run = 0;
-    for (u32 t = 0; t < tiles; t++) {
-        u64 idx = ((u64)w * tiles + t) * p.B + b;
-        u32 v = tile_hist[idx];
-        tile_hist[idx] = run;
-        run += v;
+    for (u32 t0 = 0; t0 < tiles; t0 += SORT_UNROLL) {                   // loads first: a load behind every store would wait for it
+        u32 v[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) v[j] = t0 + j < tiles ? tile_hist[((u64)w * tiles + t0 + j) * p.B + b] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) if (t0 + j < tiles) { tile_hist[((u64)w * tiles + t0 + j) * p.B + b] = run; run += v[j]; }
     }
     hist[g] = run;
 }
@@ -242,12 +249,18 @@ __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__res
     for (u32 b = threadIdx.x; b < p.B; b += blockDim.x) cnt[b] = off[b] + pre[b];
     __syncthreads();
     u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
-    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        u32 d = digits[(u64)w * n + k];
-        u32 a = d & 0x7fffu;
-        if (a) {
-            u32 pos = atomicAdd(&cnt[a - 1], 1u);
-            if (pos < sorted_cap) sorted[pos] = (u32)k | ((d & 0x8000u) << 16);
+    const unsigned short *dg = digits + (u64)w * n;
+    for (u64 k0 = lo + threadIdx.x; k0 < hi; k0 += (u64)SORT_UNROLL * blockDim.x) {
+        u32 dv[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u64 k = k0 + (u64)j * blockDim.x; dv[j] = k < hi ? (u32)dg[k] : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) {
+            u32 d = dv[j], a = d & 0x7fffu;
+            if (a) {
+                u32 pos = atomicAdd(&cnt[a - 1], 1u);
+                if (pos < sorted_cap) sorted[pos] = (u32)(k0 + (u64)j * blockDim.x) | ((d & 0x8000u) << 16);
+            }
         }
     }
 }
@@ -263,9 +276,14 @@ __global__ void __launch_bounds__(512) k_msm_coarse_hist(const unsigned short *_
     for (u32 b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
-    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        u32 a = digits[(u64)w * n + k] & 0x7fffu;
-        if (a) atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
+    // the loads of SORT_UNROLL iterations are issued together: one at a time, every iteration waits a full memory latency
+    const unsigned short *dg = digits + (u64)w * n;
+    for (u64 k0 = lo + threadIdx.x; k0 < hi; k0 += (u64)SORT_UNROLL * blockDim.x) {
+        u32 a[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u64 k = k0 + (u64)j * blockDim.x; a[j] = k < hi ? (dg[k] & 0x7fffu) : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) if (a[j]) atomicAdd(&cnt[(a[j] - 1) >> p.fine_bits], 1u);
     }
     __syncthreads();
     u32 *out = tile_hist + ((u64)w * tiles + tile) * nb;
@@ -281,12 +299,18 @@ __global__ void __launch_bounds__(512) k_msm_coarse_scatter(const unsigned short
     for (u32 b = threadIdx.x; b < nb; b += blockDim.x) cnt[b] = off[b] + pre[b];
     __syncthreads();
     u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
-    for (u64 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        u32 d = digits[(u64)w * n + k];
-        u32 a = d & 0x7fffu;
-        if (a) {
-            u32 pos = atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
-            if (pos < cap) tmp[pos] = (u32)k | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
+    const unsigned short *dg = digits + (u64)w * n;
+    for (u64 k0 = lo + threadIdx.x; k0 < hi; k0 += (u64)SORT_UNROLL * blockDim.x) {
+        u32 dv[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u64 k = k0 + (u64)j * blockDim.x; dv[j] = k < hi ? (u32)dg[k] : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) {
+            u32 d = dv[j], a = d & 0x7fffu;
+            if (a) {
+                u32 pos = atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
+                if (pos < cap) tmp[pos] = (u32)(k0 + (u64)j * blockDim.x) | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
+            }
         }
     }
 }
@@ -305,7 +329,13 @@ __global__ void __launch_bounds__(1024) k_msm_bin_offsets(u32 *__restrict__ tile
         if (g < n_bins) {
             u32 w = g / nb, b = g % nb;
             u32 *col = tile_hist + (u64)w * tiles * nb + b;
-            for (u32 k = 0; k < tiles; k++) { u32 v = col[(u64)k * nb]; col[(u64)k * nb] = run; run += v; }
+            for (u32 k0 = 0; k0 < tiles; k0 += SORT_UNROLL) {           // loads first: a load behind every store would wait for it
+                u32 v[SORT_UNROLL];
+#pragma unroll
+                for (u32 j = 0; j < SORT_UNROLL; j++) v[j] = k0 + j < tiles ? col[(u64)(k0 + j) * nb] : 0u;
+#pragma unroll
+                for (u32 j = 0; j < SORT_UNROLL; j++) if (k0 + j < tiles) { col[(u64)(k0 + j) * nb] = run; run += v[j]; }
+            }
         }
         u32 incl = run;                               // inclusive scan over the workgroup: inside the wave, then over the 16 wave sums
 #pragma unroll
@@ -330,7 +360,13 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
     const u32 s = coarse_off[(u64)w * nb + bin], e = coarse_off[(u64)w * nb + bin + 1];
     if (t < F) cnt[t] = 0;
     __syncthreads();
-    for (u32 k = s + t; k < e; k += blockDim.x) atomicAdd(&cnt[(tmp[k] >> 24) & 127u], 1u);
+    for (u32 k0 = s + t; k0 < e; k0 += SORT_UNROLL * blockDim.x) {
+        u32 v[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u32 k = k0 + j * blockDim.x; v[j] = k < e ? tmp[k] : 0xffffffffu; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) if (k0 + j * blockDim.x < e) atomicAdd(&cnt[(v[j] >> 24) & 127u], 1u);
+    }
     __syncthreads();
     u32 own = t < F ? cnt[t] : 0;
     if (t < F) scan[t] = own;
@@ -348,10 +384,17 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
     }
     if (t == 0 && bin == nb - 1 && w == p.W - 1) offsets[(u64)p.W * p.B] = e;
     __syncthreads();
-    for (u32 k = s + t; k < e; k += blockDim.x) {
-        u32 v = tmp[k];
-        u32 pos = atomicAdd(&cnt[(v >> 24) & 127u], 1u);
-        if (pos < cap) sorted[pos] = v & 0x80ffffffu;
+    for (u32 k0 = s + t; k0 < e; k0 += SORT_UNROLL * blockDim.x) {
+        u32 v[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u32 k = k0 + j * blockDim.x; v[j] = k < e ? tmp[k] : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) {
+            if (k0 + j * blockDim.x < e) {
+                u32 pos = atomicAdd(&cnt[(v[j] >> 24) & 127u], 1u);
+                if (pos < cap) sorted[pos] = v[j] & 0x80ffffffu;
+            }
+        }
     }
 }
 
