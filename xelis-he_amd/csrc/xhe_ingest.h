@@ -44,6 +44,7 @@ struct host_batch {
     std::vector<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
     std::vector<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
     std::vector<u32> bulk_decs;            // positions in decs[] of every other point
+    std::vector<u32> sig_keys;             // point index of every distinct key a signature of the batch is checked against
     std::vector<dev_op> ops;               // sorted by slot
     std::vector<dev_sig> sigs;
     std::vector<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
@@ -126,6 +127,14 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         if (early == 0) hb.bulk_decs.push_back((u32)hb.decs.size());
         hb.decs.push_back({off, early, 0u}); hb.rp_dec_tx.push_back(rp_tx);
         return hb.n_static + (u32)hb.decs.size() - 1;
+    };
+    std::unordered_map<u32, u32> sig_key_slot;        // point idx of a signing key -> position in sig_keys
+    auto key_slot_of = [&](u32 pt) -> u32 {
+        auto it = sig_key_slot.find(pt);
+        if (it != sig_key_slot.end()) return it->second;
+        u32 slot = (u32)hb.sig_keys.size();
+        hb.sig_keys.push_back(pt); sig_key_slot.emplace(pt, slot);
+        return slot;
     };
     std::unordered_map<u32, u32> account_pt;          // account idx -> point idx
     std::unordered_map<u64, u32> signer_pt;           // byte offset of a signer key -> point idx
@@ -215,6 +224,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         {
             dev_sig s{}; s.tx = (u32)i; s.key_pt = d.src_pt; s.key_off = rec + t.pre_off + 1; s.msg_off = rec + t.pre_off; s.msg_len = t.pre_len + 65u * t.n_multisig;
             s.hash_idx = 0xffffffffu; s.sig_off = rec + t.sig_off; s.err_key = errkey(ST_SIGNATURE, 0, 0, XHE_ERR_SIGNATURE); s.key_err_key = 0;
+            s.key_slot = key_slot_of(s.key_pt);
             hb.sigs.push_back(s);
         }
         // multisig (verify.rs:259-292)
@@ -234,6 +244,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                         dev_sig s{}; s.tx = (u32)i; s.key_pt = kp; s.key_off = koff; s.msg_off = 0; s.msg_len = 32; s.hash_idx = d.hash_idx;
                         s.sig_off = rec + t.ms_off + 65ull * k + 1; s.err_key = errkey(ST_MULTISIG, k, 3, XHE_ERR_SIGNATURE);
                         s.key_err_key = errkey(ST_MULTISIG, k, 2, XHE_ERR_DECOMPRESSION);
+                        s.key_slot = key_slot_of(kp);
                         hb.sigs.push_back(s);
                     }
                 }

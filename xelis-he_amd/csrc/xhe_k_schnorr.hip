@@ -86,33 +86,51 @@ __device__ __forceinline__ qd_point qd_add_cached(const qd_point &p, const fe &c
 
 static constexpr u32 SIG_QUADS = 16;          // signatures per 64-thread workgroup
 
-__device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, u32 (*tab)[10][64], const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
-                                               const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
+// Table of one key per quad of lanes: for j < SIG_KEY_POS the multiples 0..8 of 2^(64 j) P in cached form.  Keys sign many
+// transactions of a batch (an account's whole chain), and with the table a signature costs 64 doublings + 64 additions instead
+// of 256 + 72.  (An undecodable key left the identity in pts[]; k_sig_final reports it.)
+__global__ void __launch_bounds__(64) k_sig_key_tables(const u32 *__restrict__ sig_keys, u32 n_keys, const u32 *__restrict__ pts, u32 *__restrict__ key_tab) {
     const u32 lane = threadIdx.x, role = lane & 3;
+    for (u32 group = blockIdx.x; group * SIG_QUADS < n_keys; group += gridDim.x) {
+        const u32 kq = group * SIG_QUADS + (lane >> 2);
+        const u32 k = kq < n_keys ? kq : n_keys - 1;         // spare quads repeat the last key and store nothing
+        ge_niels pn = ge_niels_load(pts + 32ull * sig_keys[k]);
+        qd_point cur = qd_from_ge(ge_from_niels_affine(pn), role);
+#pragma unroll 1
+        for (u32 j = 0; j < SIG_KEY_POS; j++) {
+            qd_point m = qd_identity(role);
+            u32 *dst = key_tab + ((u64)k * SIG_KEY_POS + j) * 9 * SIG_KEY_ENTRY_WORDS + 10 * role;
+#pragma unroll 1
+            for (u32 mult = 0; mult < 9; mult++) {
+                fe c = qd_to_cached(m, role);
+                if (kq < n_keys) {
+#pragma unroll
+                    for (int l = 0; l < 10; l++) dst[mult * SIG_KEY_ENTRY_WORDS + l] = c.v[l];
+                }
+                m = qd_add(m, cur, role);
+            }
+            if (j + 1 < SIG_KEY_POS) {
+#pragma unroll 1
+                for (u32 d = 0; d < 256 / SIG_KEY_POS; d++) cur = qd_double(cur, role);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+                                               const u32 *__restrict__ key_tab, const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
+    const u32 lane = threadIdx.x, role = lane & 3;
+    constexpr u32 ROUNDS = 64 / SIG_KEY_POS;   // 4-bit digits per position
     for (u32 group = block; group * SIG_QUADS < n; group += n_blocks) {
     const u32 q = group * SIG_QUADS + (lane >> 2);
     const u32 i = q < n ? q : n - 1;           // spare quads repeat the last signature and store nothing
     const dev_sig sg = sigs[i];
     u32 sw[8], ew[8];
     load_words_unaligned(sw, bytes + sg.sig_off); load_words_unaligned(ew, bytes + sg.sig_off + 32);
-
-    // table of k * P, k = 0..8 (an undecodable key left the identity in pts[]; the last kernel reports it)
-    {
-        ge_niels pn = ge_niels_load(pts + 32ull * sg.key_pt);
-        qd_point P = qd_from_ge(ge_from_niels_affine(pn), role);
-        // multiples 0..8 of P, each written to the table as soon as it exists (one running point instead of nine live ones
-        // keeps the kernel's register count low enough to share a SIMD with two decode wavefronts)
-        qd_point cur = qd_identity(role);
-#pragma unroll 1
-        for (int k = 0; k < 9; k++) {
-            fe c = qd_to_cached(cur, role);
-#pragma unroll
-            for (int l = 0; l < 10; l++) tab[k][l][lane] = c.v[l];
-            cur = qd_add(cur, P, role);
-        }
-    }
-    // Q = e * P with signed radix-16 digits in [-8, 8], most significant first.  The carry into digit k depends on
-    // all lower digits, so the carries are worked out first, one bit per digit.
+    const u32 *tab = key_tab + (u64)sg.key_slot * SIG_KEY_TABLE_WORDS + 10 * role;
+    // Q = e * P with signed radix-16 digits in [-8, 8]: digit 16 j + r of e multiplies 2^(64 j) P, so the SIG_KEY_POS positions
+    // share the doublings.  The carry into digit k depends on all lower digits, so the carries are worked out first, one bit
+    // per digit.
     qd_point Q = qd_identity(role);
     {
         u64 carry_bits = 0;
@@ -123,15 +141,22 @@ __device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, u32 (*ta
             carry = v > 8 ? 1u : 0u;
         }
 #pragma unroll 1
-        for (int k = 63; k >= 0; k--) {
-            Q = qd_double(qd_double(qd_double(qd_double(Q, role), role), role), role);
-            u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + (u32)((carry_bits >> k) & 1);
-            bool negative = v > 8;
-            u32 mag = negative ? 16 - v : v;
-            fe c;
+        for (int r = (int)ROUNDS - 1; r >= 0; r--) {
+            // this round's table entries are requested before the doublings
+            fe c[SIG_KEY_POS]; bool negative[SIG_KEY_POS];
 #pragma unroll
-            for (int l = 0; l < 10; l++) c.v[l] = tab[mag][l][lane];
-            Q = qd_add_cached(Q, c, negative, role);
+            for (u32 j = 0; j < SIG_KEY_POS; j++) {
+                const u32 k = ROUNDS * j + (u32)r;
+                u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + (u32)((carry_bits >> k) & 1);
+                negative[j] = v > 8;
+                u32 mag = negative[j] ? 16 - v : v;
+                const u32 *src = tab + (j * 9 + mag) * SIG_KEY_ENTRY_WORDS;
+#pragma unroll
+                for (int l = 0; l < 10; l++) c[j].v[l] = src[l];
+            }
+            Q = qd_double(qd_double(qd_double(qd_double(Q, role), role), role), role);
+#pragma unroll
+            for (u32 j = 0; j < SIG_KEY_POS; j++) Q = qd_add_cached(Q, c[j], negative[j], role);
         }
     }
     // R = s * H (32 windows of 8 bits, fixed-base table) - Q
@@ -149,9 +174,8 @@ __device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, u32 (*ta
 // One launch for the two independent parts: workgroups [0, point_blocks) compute the points, the others absorb the
 // message blocks (both grid-stride over their share).
 __global__ void __launch_bounds__(64) k_sig_point_absorb(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
-                                                         const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
-    __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
-    if (blockIdx.x < point_blocks) sig_point_work(blockIdx.x, point_blocks, tab, bytes, sigs, n, pts, htab, r_out);
+                                                         const u32 *__restrict__ key_tab, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
+    if (blockIdx.x < point_blocks) sig_point_work(blockIdx.x, point_blocks, bytes, sigs, n, key_tab, htab, r_out);
     else sig_absorb_work(blockIdx.x - point_blocks, gridDim.x - point_blocks, bytes, sigs, n, state);
 }
 
@@ -196,12 +220,17 @@ __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, 
     if (diff) raise_err(tx_err, sg.tx, sg.err_key);
 }
 
-void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state) {
+void launch_sig_key_tables(hipStream_t st, const u32 *sig_keys, u32 n_keys, const u32 *pts, u32 *key_tab) {
+    if (!n_keys) return;
+    u32 blocks = grid_for(n_keys, SIG_QUADS);
+    hipLaunchKernelGGL(k_sig_key_tables, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
+}
+void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *htab, u32 *r_out, u64 *state) {
     if (!n) return;
     u32 pb = grid_for(n, SIG_QUADS), ab = grid_for(n, 64);
     if (pb > SIG_MAX_WAVES) pb = SIG_MAX_WAVES;
     if (ab > SIG_MAX_WAVES) ab = SIG_MAX_WAVES;
-    hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, pts, htab, r_out, state);
+    hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, key_tab, htab, r_out, state);
 }
 void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err) {
     if (n) hipLaunchKernelGGL(k_sig_final, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state, r_in, ok, ms_hash, tx_err);

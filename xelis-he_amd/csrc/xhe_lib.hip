@@ -180,14 +180,14 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
+    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     dev_buf arena_up, arena_ws;   // the two blocks every buffer above is a range of: uploaded tables, workspace
     std::vector<u32> group_off;   // per lg: offset into group_txs
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
+        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws})
             b->release();
@@ -452,7 +452,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         part(in->multisig_signers, hb.signers_base, 32 * hb.n_signer_keys);
         part(zeros, hb.signers_base + 32 * hb.n_signer_keys, 64);
     }
-    UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(bulk_decs, hb.bulk_decs); UP(ops, hb.ops); UP(sigs, hb.sigs);
+    UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(bulk_decs, hb.bulk_decs); UP(sig_keys, hb.sig_keys); UP(ops, hb.ops); UP(sigs, hb.sigs);
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
     UP(tx_err0, hb.tx_err); UP(apply_err0, hb.apply_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
@@ -466,7 +466,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     RS(gh, 72ull * n_parts); RS(gh_sums, 72ull * 256); RS(rp_ctx, 36ull * RPC_SCALARS * hb.n_txs); RS(rp_acc, 72ull * hb.nm_cap);
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
-    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.sigs.size()); RS(sig_r, 128ull * hb.sigs.size());
+    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.sigs.size()); RS(sig_r, 128ull * hb.sigs.size()); RS(sig_tab, 4ull * SIG_KEY_TABLE_WORDS * hb.sig_keys.size());
     // partial column sums of the range-proof scalar matrix: one row per tile of transactions
     {
         u64 worst = 0;
@@ -699,7 +699,8 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_keys, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s1));             // every point that is not the ledger scan's
     launch_blake3_preimages(ssig, bytes, txs, B->ms_hash_tx.as<u32>(), (u32)hb.ms_hash_tx.size(), B->ms_hash.as<u8>());
-    launch_sig_point_absorb(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>(), B->sig_state.as<u64>());
+    launch_sig_key_tables(ssig, B->sig_keys.as<u32>(), (u32)hb.sig_keys.size(), pts, B->sig_tab.as<u32>());
+    launch_sig_point_absorb(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_tab.as<u32>(), ctx->htab.as<u32>(), B->sig_r.as<u32>(), B->sig_state.as<u64>());
     launch_sig_final(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, B->sig_state.as<u64>(), B->sig_r.as<u32>(), ok, B->ms_hash.as<u8>(), tx_err);
     HIPCHK(ctx, tm.close("signatures", ssig));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[1], ssig));

@@ -94,6 +94,9 @@ static inline u64 transcript_stream_cap_words() {
 }
 
 // one per signature to verify
+// Per distinct signing key: SIG_KEY_POS positions (2^(64 j) P) x multiples 0..8, each as the four 10-limb multiplicands of
+// the "cached" form (Y - X, Y + X, Z, 2d T): 40 words per entry.
+static constexpr unsigned SIG_KEY_POS = 4, SIG_KEY_ENTRY_WORDS = 40, SIG_KEY_TABLE_WORDS = SIG_KEY_POS * 9 * SIG_KEY_ENTRY_WORDS;
 struct dev_sig {
     u32 tx;
     u32 key_pt;              // decoded public key
@@ -103,6 +106,7 @@ struct dev_sig {
     u64 sig_off;             // s || e
     u32 err_key;             // key raised when the signature does not verify
     u32 key_err_key;         // key raised when the public key does not decode (0 = checked elsewhere)
+    u32 key_slot;            // position of the key among the batch's distinct signing keys (its table of multiples)
 };
 
 }  // namespace xhe
