@@ -1,11 +1,13 @@
 // Schnorr signature verification (/root/reference/src/elgamal.rs:38-65): accept iff
-// e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Three parts, the first two independent of each other and run as the
-// two kinds of workgroups of one launch (k_sig_point_absorb):
+// e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Four parts:
+//   key tables     four lanes per distinct signing key (k_sig_key_tables): the multiples 0..8 of 2^(64 j) P, j < 4 -- a key
+//                  signs every transaction of its account's chain, so the 192 doublings are paid once per key;
 //   absorb         thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
 //                  held in registers (the bulk of the hashing: 19 of the 20 permutations for a one-transfer
-//                  transaction) -- needs no point, so it runs beside the point kernel;
+//                  transaction) -- needs no point, so it runs beside the point part, as the other kind of workgroup of
+//                  the same launch (k_sig_point_absorb);
 //   point          four lanes per signature (xhe_quad.h): s*H from the 8-bit fixed-base table, e*P with signed
-//                  4-bit windows over a table of 0..8 P kept in LDS, R = s*H - e*P as an XYZT record;
+//                  4-bit digits over the key's table (16 rounds of 4 doublings + 4 additions), R = s*H - e*P as an XYZT record;
 //   k_sig_final    thread per signature: encodes R, absorbs the message tail || enc(R) || padding, squeezes,
 //                  reduces mod l and compares with e.
 // A multisig co-signature hashes the 32-byte BLAKE3 digest of the pre-image instead of the message
