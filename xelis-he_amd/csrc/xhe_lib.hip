@@ -162,6 +162,7 @@ struct xhe_ctx {
     stage_timer timer;
     dev_pool pool;                 // blocks of freed batches
     void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
+    u32 *verdict_host = nullptr;                     // 64 pinned bytes the verdict words are read back into
     // level-0 workspace
     dev_buf in_bytes, scalars, niels, ok, result, xyzt;
     msm_workspace msm;
@@ -286,7 +287,8 @@ xhe_ctx *xhe_create(int device_id) {
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess && hipStreamCreate(&ctx->side[2]) == hipSuccess;
     for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { g_create_error = "creating the HIP streams and events failed"; xhe_destroy(ctx); return nullptr; }
+    ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { g_create_error = "creating the HIP streams, events and read-back buffer failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
 }
 
@@ -299,6 +301,7 @@ void xhe_destroy(xhe_ctx *ctx) {
         b->release();
     ctx->pool.drain();
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->verdict_host) (void)hipHostFree(ctx->verdict_host);
     ctx->timer.release();
     for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
@@ -757,7 +760,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, tm.mark("verdict", st));
     launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
     HIPCHK(ctx, tm.mark("end", st));
-    u32 host[16];
+    u32 *host = ctx->verdict_host;
     HIPCHK(ctx, hipMemcpyAsync(host, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
     host_mark("all enqueued");
     HIPCHK(ctx, hipStreamSynchronize(st));
