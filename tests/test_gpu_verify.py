@@ -447,11 +447,14 @@ def test_transcripts_on_one_lane_per_transaction(engine, oracle, monkeypatch):
     assert g == r and g[0] == 0 and g[2] == 33
 
 
-@pytest.mark.parametrize("n_senders", [1, 3, 150])
-def test_signatures_through_key_tables(engine, oracle, n_senders):
-    """The signature kernel adds from a table of multiples built once per distinct signing key: one key signing the whole
-    batch (the reference bench's single chain), a few keys, and as many keys as transactions give the oracle's verdicts, also
-    with a flipped bit in s or e of the first, a middle and the last signature (the error names that transaction)."""
+@pytest.mark.parametrize("n_senders,forced", [(1, None), (3, None), (150, None), (150, "1"), (1, "0")])
+def test_signatures_through_key_tables(engine, oracle, monkeypatch, n_senders, forced):
+    """Batches whose keys sign six or more transactions each add from a table of multiples built once per distinct signing
+    key; the others build the table per signature (XHE_SIG_KEY_TABLES forces either).  One key signing the whole batch (the
+    reference bench's single chain), a few keys, and as many keys as transactions give the oracle's verdicts on both paths,
+    also with a flipped bit in s or e of the first, a middle and the last signature (the error names that transaction)."""
+    if forced is not None:
+        monkeypatch.setenv("XHE_SIG_KEY_TABLES", forced)
     sb = SyntheticBatch(150, n_transfers=1, n_senders=n_senders, seed=b"key-tables-%d" % n_senders)
     ref, ref_cts, _ = _raw_verify(None, oracle, None, sb)
     got, cts, _ = _raw_verify(engine.lib, engine, engine.ctx, sb)
@@ -462,4 +465,4 @@ def test_signatures_through_key_tables(engine, oracle, n_senders):
         bad[offs[tx + 1] - back] ^= 0x10
         g, _, _ = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
         r, _, _ = _raw_verify(None, oracle, None, sb, bytes(bad))
-        assert g == r and g[0] == 0 and g[2] == tx, (n_senders, tx, back, g, r)
+        assert g == r and g[0] == 0 and g[2] == tx, (n_senders, forced, tx, back, g, r)

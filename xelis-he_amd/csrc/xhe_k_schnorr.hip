@@ -1,7 +1,8 @@
 // Schnorr signature verification (/root/reference/src/elgamal.rs:38-65): accept iff
 // e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Four parts:
 //   key tables     four lanes per distinct signing key (k_sig_key_tables): the multiples 0..8 of 2^(64 j) P, j < 4 -- a key
-//                  signs every transaction of its account's chain, so the 192 doublings are paid once per key;
+//                  signs every transaction of its account's chain, so the 192 doublings are paid once per key (batches with
+//                  few signatures per key skip this part and use k_sig_point_absorb_own_table);
 //   absorb         thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
 //                  held in registers (the bulk of the hashing: 19 of the 20 permutations for a one-transfer
 //                  transaction) -- needs no point, so it runs beside the point part, as the other kind of workgroup of
@@ -173,11 +174,79 @@ __device__ __forceinline__ void sig_point_work(u32 block, u32 n_blocks, const u8
     }
 }
 
+// The same with the table of multiples 0..8 of P built per signature in LDS (256 doublings + 72 additions): for batches whose
+// keys sign too few transactions each for a table per key to pay.
+__device__ __forceinline__ void sig_point_work_own_table(u32 block, u32 n_blocks, u32 (*tab)[10][64], const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+                                               const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out) {
+    const u32 lane = threadIdx.x, role = lane & 3;
+    for (u32 group = block; group * SIG_QUADS < n; group += n_blocks) {
+    const u32 q = group * SIG_QUADS + (lane >> 2);
+    const u32 i = q < n ? q : n - 1;           // spare quads repeat the last signature and store nothing
+    const dev_sig sg = sigs[i];
+    u32 sw[8], ew[8];
+    load_words_unaligned(sw, bytes + sg.sig_off); load_words_unaligned(ew, bytes + sg.sig_off + 32);
+
+    // table of k * P, k = 0..8 (an undecodable key left the identity in pts[]; the last kernel reports it)
+    {
+        ge_niels pn = ge_niels_load(pts + 32ull * sg.key_pt);
+        qd_point P = qd_from_ge(ge_from_niels_affine(pn), role);
+        // multiples 0..8 of P, each written to the table as soon as it exists (one running point instead of nine live ones
+        // keeps the kernel's register count low enough to share a SIMD with two decode wavefronts)
+        qd_point cur = qd_identity(role);
+#pragma unroll 1
+        for (int k = 0; k < 9; k++) {
+            fe c = qd_to_cached(cur, role);
+#pragma unroll
+            for (int l = 0; l < 10; l++) tab[k][l][lane] = c.v[l];
+            cur = qd_add(cur, P, role);
+        }
+    }
+    // Q = e * P with signed radix-16 digits in [-8, 8], most significant first.  The carry into digit k depends on
+    // all lower digits, so the carries are worked out first, one bit per digit.
+    qd_point Q = qd_identity(role);
+    {
+        u64 carry_bits = 0;
+        u32 carry = 0;
+        for (u32 k = 0; k < 64; k++) {
+            carry_bits |= (u64)carry << k;
+            u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + carry;
+            carry = v > 8 ? 1u : 0u;
+        }
+#pragma unroll 1
+        for (int k = 63; k >= 0; k--) {
+            Q = qd_double(qd_double(qd_double(qd_double(Q, role), role), role), role);
+            u32 v = ((ew[k >> 3] >> ((k & 7) * 4)) & 15) + (u32)((carry_bits >> k) & 1);
+            bool negative = v > 8;
+            u32 mag = negative ? 16 - v : v;
+            fe c;
+#pragma unroll
+            for (int l = 0; l < 10; l++) c.v[l] = tab[mag][l][lane];
+            Q = qd_add_cached(Q, c, negative, role);
+        }
+    }
+    // R = s * H (32 windows of 8 bits, fixed-base table) - Q
+    qd_point R = qd_identity(role);
+#pragma unroll 1
+    for (u32 w = 0; w < 32; w++) {
+        u32 b = (sw[w >> 2] >> ((w & 3) * 8)) & 255;
+        R = qd_madd(R, htab + 32ull * (w * 256 + b), false, role);
+    }
+    R = qd_add_cached(R, qd_to_cached(Q, role), true, role);
+    if (q < n) qd_store(r_out + 32ull * q, R, role);
+    }
+}
+
 // One launch for the two independent parts: workgroups [0, point_blocks) compute the points, the others absorb the
 // message blocks (both grid-stride over their share).
 __global__ void __launch_bounds__(64) k_sig_point_absorb(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
                                                          const u32 *__restrict__ key_tab, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
     if (blockIdx.x < point_blocks) sig_point_work(blockIdx.x, point_blocks, bytes, sigs, n, key_tab, htab, r_out);
+    else sig_absorb_work(blockIdx.x - point_blocks, gridDim.x - point_blocks, bytes, sigs, n, state);
+}
+__global__ void __launch_bounds__(64) k_sig_point_absorb_own_table(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+                                                                   const u32 *__restrict__ pts, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
+    __shared__ u32 tab[9][10][64];            // multiples 0..8 of P: [multiple][limb][lane], each lane its own cached multiplicand
+    if (blockIdx.x < point_blocks) sig_point_work_own_table(blockIdx.x, point_blocks, tab, bytes, sigs, n, pts, htab, r_out);
     else sig_absorb_work(blockIdx.x - point_blocks, gridDim.x - point_blocks, bytes, sigs, n, state);
 }
 
@@ -227,12 +296,13 @@ void launch_sig_key_tables(hipStream_t st, const u32 *sig_keys, u32 n_keys, cons
     u32 blocks = grid_for(n_keys, SIG_QUADS);
     hipLaunchKernelGGL(k_sig_key_tables, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
 }
-void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *htab, u32 *r_out, u64 *state) {
+void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state) {
     if (!n) return;
     u32 pb = grid_for(n, SIG_QUADS), ab = grid_for(n, 64);
     if (pb > SIG_MAX_WAVES) pb = SIG_MAX_WAVES;
     if (ab > SIG_MAX_WAVES) ab = SIG_MAX_WAVES;
-    hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, key_tab, htab, r_out, state);
+    if (key_tab) hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, key_tab, htab, r_out, state);
+    else hipLaunchKernelGGL(k_sig_point_absorb_own_table, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, pts, htab, r_out, state);
 }
 void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err) {
     if (n) hipLaunchKernelGGL(k_sig_final, dim3(grid_for(n, 64)), dim3(64), 0, st, bytes, sigs, n, state, r_in, ok, ms_hash, tx_err);

@@ -74,7 +74,8 @@ void launch_blake3_preimages(hipStream_t st, const u8 *bytes, const dev_tx *txs,
 // signatures: sponge state after the whole blocks of pk || msg (25 x n words) | R = s*H - e*P as XYZT records | hash tail, compare
 // per distinct signing key the table of multiples the point kernel adds from (SIG_KEY_TABLE_WORDS words each)
 void launch_sig_key_tables(hipStream_t st, const u32 *sig_keys, u32 n_keys, const u32 *pts, u32 *key_tab);
-void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *htab, u32 *r_out, u64 *state);
+// key_tab == null: every signature builds the table of its key's multiples itself (from pts)
+void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state);
 void launch_sig_final(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u64 *state, const u32 *r_in, const u8 *ok, const u8 *ms_hash, u32 *tx_err);
 // ledger scan
 static constexpr u32 SCAN_K = 4;          // operations per thread
