@@ -4,8 +4,9 @@
  * are the Rust calls named beside each entry point.  Every entry point takes plain pointers and sizes;
  * all multi-byte integers in buffers are little-endian unless stated; all buffers are caller-owned
  * host memory unless the name says "_dev".  Return value: 0 = the call ran (the verdict is in the out
- * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns three HIP streams
- * there, all at the default priority) and must not be used from two threads at once; different contexts
+ * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns four HIP streams
+ * there, all at the default priority: with the default GPU_MAX_HW_QUEUES = 4 that is every hardware queue of the
+ * process, so a caller's own stream shares a queue with one of them) and must not be used from two threads at once; different contexts
  * are independent.
  */
 #ifndef XHE_H
@@ -61,6 +62,16 @@ const char *xhe_last_error(const xhe_ctx *ctx);
  * n may be 0 (result: identity).  Returns XHE_E_DECODE if a point does not decode. */
 int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, const uint8_t *points32,
                         uint8_t out32[32], uint8_t *is_identity);
+
+/* xhe_msm_vartime for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): same arguments and results, but the staging buffers and the whole workspace are ranges
+ * of one file-scope device array of 12 MiB that every GPU the library runs on holds until the process ends; the call makes
+ * no hipMalloc / hipFree.  No counterpart in the reference.  n above XHE_MSM_STATIC_MAX_TERMS (or a workspace that does not
+ * fit the array) is XHE_E_ARG with a message in xhe_last_error().  All calls on one GPU share that GPU's array, contexts
+ * included: calls that overlap in time on one GPU race, so serialise them. */
+#define XHE_MSM_STATIC_MAX_TERMS 4096
+int32_t xhe_msm_vartime_static(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, const uint8_t *points32,
+                               uint8_t out32[32], uint8_t *is_identity);
 
 /* CompressedRistretto::decompress over a batch (src/compressed.rs:28-33,57-62,78-83,100-105):
  * out_xyzt128 receives canonical X,Y,Z,T (4 x 32 bytes) per point, ok[i] = 1 when the encoding is valid

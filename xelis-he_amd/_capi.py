@@ -33,6 +33,8 @@ def load_library():
     lib.xhe_last_error.argtypes = [ctypes.c_void_p]
     lib.xhe_msm_vartime.restype = ctypes.c_int32
     lib.xhe_msm_vartime.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, u8p, u8p]
+    lib.xhe_msm_vartime_static.restype = ctypes.c_int32
+    lib.xhe_msm_vartime_static.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, u8p, u8p]
     lib.xhe_ristretto_decompress_batch.restype = ctypes.c_int32
     lib.xhe_ristretto_decompress_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, u8p, u8p]
     lib.xhe_ristretto_compress_batch.restype = ctypes.c_int32
@@ -76,6 +78,14 @@ class Engine:
         n = len(scalars32) // 32
         out, ident = (ctypes.c_uint8 * 32)(), (ctypes.c_uint8 * 1)()
         self._check(self.lib.xhe_msm_vartime(self.ctx, n, scalars32, points32, out, ident))
+        return bytes(out), bool(ident[0])
+
+    def msm_vartime_static(self, scalars32: bytes, points32: bytes):
+        """xhe_msm_vartime_static: the same operator from the library's static device array (no allocation, bounded size)."""
+        assert len(scalars32) == len(points32) and len(scalars32) % 32 == 0
+        n = len(scalars32) // 32
+        out, ident = (ctypes.c_uint8 * 32)(), (ctypes.c_uint8 * 1)()
+        self._check(self.lib.xhe_msm_vartime_static(self.ctx, n, scalars32, points32, out, ident))
         return bytes(out), bool(ident[0])
 
     def decompress_batch(self, in32: bytes):

@@ -24,6 +24,12 @@ using namespace xhe;
 
 static std::string g_create_error;
 
+// Memory of xhe_msm_vartime_static: the staging buffers and the whole workspace of one multiscalar multiplication of at
+// most XHE_MSM_STATIC_MAX_TERMS terms.  Every GPU the library runs on holds its own copy until the process ends; host
+// code reaches it only through the address hipGetSymbolAddress returns for the current device (xhe_create).
+static constexpr size_t MSM_STATIC_BYTES = 12ull << 20;
+static __device__ __align__(256) unsigned char scratch[MSM_STATIC_BYTES];
+
 // Device blocks released by one batch are kept for the next: a batch takes two blocks (its uploaded tables, its
 // workspace), and in a steady stream of batches of similar size neither costs a hipMalloc / hipFree pair (each of which
 // is tens of microseconds and, for hipFree, a device-wide synchronisation).
@@ -175,6 +181,7 @@ struct xhe_ctx {
     u32 gen_tab_cap = 0;       // the capacity gen_tab was built for, 0 = none
     dev_buf static_partials, static_sum;
     bool tables_ready = false;
+    unsigned char *static_scratch = nullptr;   // this device's copy of `scratch`
 };
 
 struct xhe_batch {
@@ -288,6 +295,8 @@ xhe_ctx *xhe_create(int device_id) {
     for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64, hipHostMallocDefault) == hipSuccess;
+    // the address of this device's copy of the static scratch array (the array's name itself is a host-side stand-in)
+    if (ok && hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch)) != hipSuccess) { ctx->static_scratch = nullptr; ok = false; }
     if (!ok) { g_create_error = "creating the HIP streams, events and read-back buffer failed"; xhe_destroy(ctx); return nullptr; }
     return ctx;
 }
@@ -381,6 +390,46 @@ int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, cons
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->result.p, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     ctx->timer.finish();
+    if (host[12] != 0) { set_error(ctx, "a compressed point does not decode"); return XHE_E_DECODE; }
+    memcpy(out32, host, 32);
+    if (is_identity) *is_identity = (uint8_t)host[8];
+    return 0;
+}
+
+// xhe_msm_vartime without any allocation: staging buffers and workspace are ranges of this device's static scratch array.
+int32_t xhe_msm_vartime_static(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, const uint8_t *points32, uint8_t out32[32], uint8_t *is_identity) {
+    if (!ctx || !out32 || (n && (!scalars32 || !points32))) return XHE_E_ARG;
+    if (n > XHE_MSM_STATIC_MAX_TERMS) { set_error(ctx, "xhe_msm_vartime_static: more than XHE_MSM_STATIC_MAX_TERMS terms"); return XHE_E_ARG; }
+    if (!ctx->static_scratch) { set_error(ctx, "xhe_msm_vartime_static: the static scratch array has no device address"); return XHE_E_HIP; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u64 nn = n ? n : 1;
+    const msm_plan p = msm_make_plan(n);
+    const msm_ws_bytes need = msm_workspace_bytes(n, p);
+    // carve 256-byte aligned ranges: result, inputs, decoded points, validity marks, then the workspace
+    size_t off = 0;
+    auto carve = [&](u64 bytes) { unsigned char *q = ctx->static_scratch + off; off += (size_t)((bytes + 255) & ~255ull); return q; };
+    u32 *d_result = (u32 *)carve(64), *d_in = (u32 *)carve(nn * 32), *d_sc = (u32 *)carve(nn * 32), *d_niels = (u32 *)carve(nn * 128);
+    u8 *d_ok = (u8 *)carve(nn);
+    msm_ws w;
+    w.hist = (u32 *)carve(need.hist); w.offsets = (u32 *)carve(need.offsets); w.tile_hist = (u32 *)carve(need.tile_hist); w.sorted = (u32 *)carve(need.sorted);
+    w.buckets = (u32 *)carve(need.buckets); w.digits = (u32 *)carve(need.digits); w.chunk_sums = (u32 *)carve(need.chunk_sums); w.big_list = (u32 *)carve(need.big_list);
+    w.segs = (u32 *)carve(need.segs); w.wins = (u32 *)carve(need.wins); w.tmp = (u32 *)carve(need.tmp); w.coarse = (u32 *)carve(need.coarse);
+    if (off > MSM_STATIC_BYTES) { set_error(ctx, "xhe_msm_vartime_static: the workspace of this size does not fit the static scratch array"); return XHE_E_ARG; }
+    // the array keeps the previous call's contents: the result words (identity flag, count of undecodable points) start at zero,
+    // every other range is written before it is read (the digit kernel resets the list of oversized buckets)
+    HIPCHK(ctx, hipMemsetAsync(d_result, 0, 64, st));
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(d_in, points32, n * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_sc, scalars32, n * 32, hipMemcpyHostToDevice, st));
+        launch_decode_niels(st, d_in, n, d_niels, d_ok);
+        launch_count_bad(st, d_ok, n, d_result + 12);
+        launch_reduce_scalars(st, d_sc, n);
+    }
+    HIPCHK(ctx, msm_launch(st, d_sc, d_niels, nullptr, n, n, p, w, d_result, true, msm_deps(), nullptr, nullptr));
+    u32 *host = ctx->verdict_host;                       // pinned at context creation
+    HIPCHK(ctx, hipMemcpyAsync(host, d_result, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
     if (host[12] != 0) { set_error(ctx, "a compressed point does not decode"); return XHE_E_DECODE; }
     memcpy(out32, host, 32);
     if (is_identity) *is_identity = (uint8_t)host[8];
