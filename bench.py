@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--senders", type=int, default=1024, help="sender accounts per batch (1 = the reference bench's single chain)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="transactions of the batch the CPU baseline verifies (0 = skip)")
     ap.add_argument("--gen-threads", type=int, default=16)
+    ap.add_argument("--cpu-prover", action="store_true", help="generate the range proofs of the synthetic batch on the CPU (same bytes, slower)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo reduces through host memory, for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (only with --backend gloo)")
     return ap.parse_args()
@@ -114,7 +115,8 @@ def main():
     mixed = args.workload == "mixed"
     if mixed:
         args.txs -= args.txs % 16
-    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed)
+    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed,
+                           engine=None if (mixed or args.cpu_prover) else engine)
     gen_s = time.time() - t0
 
     handle = ctypes.c_void_p()

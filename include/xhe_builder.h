@@ -64,8 +64,25 @@ int32_t xhe_tx_finalize(const uint8_t *unsigned_record, uint64_t len, int32_t mu
 int32_t xhe_tx_apply_host(const uint8_t *record, uint64_t len, uint64_t n_accounts, const uint8_t *account_keys, uint64_t n_balances,
                           const uint32_t *balance_account, const uint8_t *balance_assets, uint8_t *balance_cts);
 
+/* GPU-assisted proving: the aggregated 64-bit range proofs of n transactions at once (RangeProof::prove_multiple as
+ * TransactionBuilder::build_unsigned calls it, src/tx/builder.rs:525-533; bulletproofs 5.2.0 of the xelis fork), every
+ * proof over m values (a power of two, at most XHE_RANGE_PROOF_GPU_MAX_VALUES).  Per proof: the Merlin transcript after
+ * "rangeproof v1", n, m and the value commitments were appended (200 bytes of STROBE state, pos, pos_begin, 6 bytes of
+ * padding), the m values and their m openings (canonical scalars), and the seed and counter of the random generator the
+ * CPU prover would draw from (SHAKE256(seed || LE64(counter)) -> wide-reduced scalar per draw; draws in order:
+ * a_blinding, s_blinding, s_L[i] and s_R[i] interleaved, t1_blinding, t2_blinding).  proofs receives 32 (9 + 2 lg) bytes
+ * per proof, lg = log2(64 m): the same bytes the CPU prover writes for the same inputs.  Creates inputs for
+ * xhe_verify_batch; not part of the verification path. */
+#define XHE_RANGE_PROOF_GPU_MAX_VALUES 16
+#define XHE_RANGE_PROOF_TRANSCRIPT_BYTES 208
+int32_t xhe_range_proofs_prove(xhe_ctx *ctx, uint64_t n, uint32_t m, const uint8_t *transcripts, const uint64_t *values, const uint8_t *openings32,
+                               const uint8_t *seeds32, const uint64_t *counters, uint8_t *proofs);
+
 typedef struct xhe_synth xhe_synth;
 xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads);
+/* the same batch, byte for byte, with the range proofs generated on ctx's GPU (ctx == NULL, or more than
+ * XHE_RANGE_PROOF_GPU_MAX_VALUES value commitments per transaction: all on the CPU) */
+xhe_synth *xhe_synth_transfers_gpu(xhe_ctx *ctx, uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads);
 /* n_groups x 16 mixed transactions over disjoint account groups: 2 multisig set-ups, 4 one-asset transfers, 4 two-asset
  * double transfers, 2 native + 2 second-asset burns, 2 co-signed transfers from the accounts set up in the same group. */
 xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads);

@@ -83,6 +83,8 @@ def _lib():
                                              ctypes.POINTER(LedgerView), ctypes.POINTER(LedgerOut), ctypes.POINTER(Verdict), ctypes.c_char_p]
         lib.xhe_synth_transfers.restype = ctypes.c_void_p
         lib.xhe_synth_transfers.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32]
+        lib.xhe_synth_transfers_gpu.restype = ctypes.c_void_p
+        lib.xhe_synth_transfers_gpu.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_mixed.restype = ctypes.c_void_p
         lib.xhe_synth_mixed.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_free.argtypes = [ctypes.c_void_p]
@@ -436,15 +438,19 @@ class TransactionBuilder:
 class SyntheticBatch:
     """benches/tx.rs:129-189 generalised: n_txs transfer transactions over n_senders sender/receiver pairs."""
 
-    def __init__(self, n_txs, n_transfers=1, n_senders=1, seed=b"synthetic", threads=None, mixed=False):
+    def __init__(self, n_txs, n_transfers=1, n_senders=1, seed=b"synthetic", threads=None, mixed=False, engine=None):
         """mixed=True: n_txs / 16 groups of mixed transactions (multisig set-ups, one- and two-asset transfers, burns,
-        co-signed transfers) over disjoint account groups; n_transfers and n_senders are ignored."""
+        co-signed transfers) over disjoint account groups; n_transfers and n_senders are ignored.
+        engine: an Engine whose GPU generates the aggregated range proofs (transfer batches only; the records are the same
+        bytes as without it)."""
         lib = _lib()
         threads = threads or min(os.cpu_count() or 1, 16)
         if mixed:
             if n_txs % 16:
                 raise ValueError("a mixed batch is made of groups of 16 transactions")
             self.handle = lib.xhe_synth_mixed(n_txs // 16, _fresh_seed(seed), threads)
+        elif engine is not None:
+            self.handle = lib.xhe_synth_transfers_gpu(engine.ctx, n_txs, n_transfers, n_senders, _fresh_seed(seed), threads)
         else:
             self.handle = lib.xhe_synth_transfers(n_txs, n_transfers, n_senders, _fresh_seed(seed), threads)
         if not self.handle:

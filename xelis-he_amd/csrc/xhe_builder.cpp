@@ -82,12 +82,17 @@ static sc inner(const std::vector<sc> &a, const std::vector<sc> &b, size_t off_a
     return acc;
 }
 
-void range_proof_prove(std::vector<u8> &out, transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings, drbg &rng) {
-    const size_t n = 64, m = values.size(), nm = n * m;
-    generators &g = gens(); g.ensure(nm);
+void range_proof_begin(transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings) {
+    const size_t n = 64, m = values.size();
     t.append_message("dom-sep", (const u8 *)"rangeproof v1", 13);
     t.append_u64("n", n); t.append_u64("m", m);
     for (size_t j = 0; j < m; j++) { u8 vb[32]; encode(vb, commit(values[j], openings[j])); t.append_point("V", vb); }
+}
+
+void range_proof_prove(std::vector<u8> &out, transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings, drbg &rng) {
+    const size_t n = 64, m = values.size(), nm = n * m;
+    generators &g = gens(); g.ensure(nm);
+    range_proof_begin(t, values, openings);
 
     sc a_blinding = rng.scalar(), s_blinding = rng.scalar();
     std::vector<sc> s_L(nm), s_R(nm);
@@ -226,7 +231,7 @@ static std::vector<bytes32> used_assets(const builder_in &in) {
     return v;
 }
 
-int build_unsigned(const builder_in &in, const keypair &source, drbg &rng, unsigned_tx &out, std::vector<asset_balance> *new_balances) {
+int build_unsigned(const builder_in &in, const keypair &source, drbg &rng, unsigned_tx &out, std::vector<asset_balance> *new_balances, pending_range_proof *defer) {
     struct transfer_c { ge C, Ds, Dr, dest; sc opening; u8 Cb[32], Dsb[32], Drb[32]; };
     std::vector<transfer_c> tc(in.type == 0 ? in.transfers.size() : 0);
     for (size_t i = 0; i < tc.size(); i++) {
@@ -336,7 +341,19 @@ int build_unsigned(const builder_in &in, const keypair &source, drbg &rng, unsig
     size_t m = 1; while (m < rp_values.size()) m <<= 1;
     while (rp_values.size() < m) { rp_values.push_back(0); rp_openings.push_back(sc_zero()); }
     std::vector<u8> rp;
-    range_proof_prove(rp, t, rp_values, rp_openings, rng);
+    if (defer) {
+        // the proof is produced elsewhere (xhe_range_proofs_prove) from exactly the state the CPU prover would start from: the
+        // transcript after the value commitments and the generator's counter; the counter then skips the proof's draws
+        // (a_blinding, s_blinding, s_L and s_R per position, t1_blinding, t2_blinding)
+        range_proof_begin(t, rp_values, rp_openings);
+        defer->t = t; defer->values = rp_values; defer->openings = rp_openings;
+        memcpy(defer->seed, rng.seed, 32); defer->ctr = rng.ctr;
+        rng.ctr += 2 * 64 * (u64)m + 4;
+        size_t lg = 6; while (((size_t)1 << lg) < 64 * m) lg++;
+        rp.assign(32 * (9 + 2 * lg), 0);
+    } else {
+        range_proof_prove(rp, t, rp_values, rp_openings, rng);
+    }
 
     out.header.clear();
     out.header.push_back(in.type); out.header.push_back(0);
@@ -348,6 +365,7 @@ int build_unsigned(const builder_in &in, const keypair &source, drbg &rng, unsig
     put(out.preimage, source.pub_bytes.data(), 32);
     put_be64(out.preimage, in.fee); put_be64(out.preimage, in.nonce);
     put(out.preimage, payload.data(), payload.size());
+    out.rp_off = out.preimage.size(); out.rp_len = rp.size();
     put(out.preimage, rp.data(), rp.size());
     put(out.preimage, commitments_bytes.data(), commitments_bytes.size());
     out.multisig.clear(); out.has_multisig = false;

@@ -58,6 +58,7 @@ struct builder_in {
 struct unsigned_tx {
     std::vector<u8> header;     // 16 bytes + extra_len table
     std::vector<u8> preimage;   // to_bytes() without multisig
+    size_t rp_off = 0, rp_len = 0;   // where the range proof lies inside the pre-image
     std::vector<std::pair<u8, bytes64>> multisig; bool has_multisig = false;
     bytes32 hash() const;       // BLAKE3 of the pre-image (builder.rs:192-195)
     std::vector<u8> sign(const keypair &kp, drbg &rng) const;   // builder.rs:203-218 -> full record
@@ -65,10 +66,22 @@ struct unsigned_tx {
 
 enum { BUILD_OK = 0, BUILD_ERR_DECOMPRESSION = 1, BUILD_ERR_INSUFFICIENT_FUNDS = 2, BUILD_ERR_FORMAT = 3, BUILD_ERR_STATE = 4 };
 
+// A range proof left to the batched GPU prover: everything RangeProof::prove_multiple starts from.
+struct pending_range_proof {
+    transcript t;                   // after "rangeproof v1", n, m and the value commitments
+    std::vector<u64> values; std::vector<sc> openings;
+    u8 seed[32]; u64 ctr;           // the random generator at the proof's first draw
+};
+
 // TransactionBuilder::build_unsigned.  new_balances (optional) receives the source's ciphertext per
-// used asset after this transaction, in the order of the emitted commitments.
+// used asset after this transaction, in the order of the emitted commitments.  With `defer` the range
+// proof is not computed: its place in the pre-image (rp_off, rp_len) holds zeros and `defer` what the
+// prover needs; the random generator ends in the state it would have after proving.
 int build_unsigned(const builder_in &in, const keypair &source, drbg &rng, unsigned_tx &out,
-                   std::vector<asset_balance> *new_balances);
+                   std::vector<asset_balance> *new_balances, pending_range_proof *defer = nullptr);
+
+// the transcript part of the proof that precedes every random draw: domain separator, n, m, value commitments
+void range_proof_begin(transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings);
 
 // aggregated 64-bit range proof over values/openings (m = power of two), appended to `out`
 void range_proof_prove(std::vector<u8> &out, transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings, drbg &rng);

@@ -5,6 +5,10 @@
 #include <map>
 #include <thread>
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "../../include/xhe_builder.h"
 #include "xhe_builder.h"
 #include "xhe_record.h"
@@ -176,9 +180,11 @@ struct xhe_synth {
 // receiver; every transaction is built against the ledger left by the previous transaction of its
 // sender.  Commitments and ciphertext chains are laid out sequentially per sender (cheap), the proofs
 // are generated by `threads` workers.
-xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads) {
+xhe_synth *xhe_synth_transfers_gpu(xhe_ctx *ctx, uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads) {
     if (!n_senders || !n_transfers || n_transfers > 255 || !seed32) return nullptr;
     if (threads < 1) threads = 1;
+    u32 m = 1; while (m < n_transfers + 1) m <<= 1;
+    const bool on_gpu = ctx != nullptr && m <= XHE_RANGE_PROOF_GPU_MAX_VALUES && n_txs > 0;
     xhe_synth *S = new xhe_synth();
     drbg root(seed32);
     const u64 FUNDS = 10000000;
@@ -198,14 +204,28 @@ xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_
         S->balance_account[2 * i] = 2 * i; S->balance_account[2 * i + 1] = 2 * i + 1;
         memcpy(&S->balance_cts[128 * i], sender_ct[i].data(), 64); memcpy(&S->balance_cts[128 * i + 64], rc.data(), 64);
     }
-    // per-transaction seeds and per-sender chains; a sender's transactions are proved in order by one
-    // worker, different senders in parallel.  With a single sender the chain is still sequential in the
-    // ciphertext but each proof only needs the ciphertext, so transactions are first "planned" (the
-    // builder is run once per tx in order inside the worker that owns the sender).
+    // Per-transaction seeds and per-sender chains: a sender's transactions are built in order by one worker (each needs
+    // the ciphertext its predecessor left), different senders in parallel.  With a GPU the aggregated range proofs of the
+    // whole batch are left out of that pass, proved together on the device, and patched in before signing; the records
+    // are the same bytes either way.
     std::vector<std::vector<u8>> recs(n_txs);
     std::vector<bytes32> seeds(n_txs);
     for (u64 k = 0; k < n_txs; k++) { u8 s[32]; root.bytes(s, 32); seeds[k] = b32(s); }
+    std::vector<unsigned_tx> unsig(on_gpu ? n_txs : 0);
+    std::vector<u64> sign_ctr(on_gpu ? n_txs : 0);
+    std::vector<u8> g_transcripts, g_openings, g_seeds, g_proofs; std::vector<u64> g_values, g_ctr;
+    if (on_gpu) {
+        g_transcripts.assign((size_t)XHE_RANGE_PROOF_TRANSCRIPT_BYTES * n_txs, 0); g_openings.resize(32ull * m * n_txs); g_seeds.resize(32 * n_txs);
+        g_values.resize((u64)m * n_txs); g_ctr.resize(n_txs);
+    }
     std::atomic<u32> next_sender(0); std::atomic<int> failed(0);
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {           // XHE_SYNTH_TIMES=1: phase times on stderr
+        if (!getenv("XHE_SYNTH_TIMES")) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[xhe synth] %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     auto worker = [&]() {
         for (;;) {
             u32 s = next_sender.fetch_add(1);
@@ -215,29 +235,76 @@ xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_
                 for (u32 j = 0; j < n_transfers; j++) { transfer_in tr; tr.asset = bytes32{}; tr.amount = 1; tr.dest = receivers[s].pub_bytes; in.transfers.push_back(tr); }
                 asset_balance b; b.asset = bytes32{}; b.balance = sender_bal[s]; b.ct = sender_ct[s]; in.balances.push_back(b);
                 drbg rng(seeds[k].data());
-                unsigned_tx u; std::vector<asset_balance> nb;
-                if (build_unsigned(in, senders[s], rng, u, &nb) != BUILD_OK) { failed = 1; return; }
-                recs[k] = u.sign(senders[s], rng);
+                std::vector<asset_balance> nb;
+                if (on_gpu) {
+                    pending_range_proof pend;
+                    if (build_unsigned(in, senders[s], rng, unsig[k], &nb, &pend) != BUILD_OK || pend.values.size() != m) { failed = 1; return; }
+                    u8 *ts = &g_transcripts[(size_t)XHE_RANGE_PROOF_TRANSCRIPT_BYTES * k];
+                    memcpy(ts, pend.t.s.st.bytes, 200); ts[200] = pend.t.s.pos; ts[201] = pend.t.s.pos_begin;
+                    for (u32 j = 0; j < m; j++) { g_values[(u64)m * k + j] = pend.values[j]; sc_tobytes(&g_openings[32ull * (m * k + j)], pend.openings[j]); }
+                    memcpy(&g_seeds[32 * k], pend.seed, 32); g_ctr[k] = pend.ctr;
+                    sign_ctr[k] = rng.ctr;
+                } else {
+                    unsigned_tx u;
+                    if (build_unsigned(in, senders[s], rng, u, &nb) != BUILD_OK) { failed = 1; return; }
+                    recs[k] = u.sign(senders[s], rng);
+                }
                 sender_bal[s] = nb[0].balance; sender_ct[s] = nb[0].ct;
             }
         }
     };
     gens().ensure(64 * 2);   // touch the lazily built tables before the workers start
+    gens().ensure(64ull * m);
     {
-        u32 m = 1; while (m < n_transfers + 1) m <<= 1;
-        gens().ensure(64ull * m);
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
     }
-    std::vector<std::thread> pool;
-    for (int i = 0; i < threads; i++) pool.emplace_back(worker);
-    for (auto &th : pool) th.join();
+    lap(on_gpu ? "transactions without range proofs" : "transactions");
+    if (!failed && on_gpu) {
+        u32 lg = 6; while ((1u << lg) < 64 * m) lg++;
+        const size_t proof_bytes = 32 * (9 + 2 * lg);
+        g_proofs.resize(proof_bytes * n_txs);
+        if (xhe_range_proofs_prove(ctx, n_txs, m, g_transcripts.data(), g_values.data(), g_openings.data(), g_seeds.data(), g_ctr.data(), g_proofs.data()) != 0) failed = 1;
+        lap("range proofs on the GPU");
+        std::atomic<u64> next_tx(0);
+        auto signer = [&]() {
+            for (;;) {
+                u64 k0 = next_tx.fetch_add(64);
+                if (k0 >= n_txs) break;
+                for (u64 k = k0; k < std::min<u64>(k0 + 64, n_txs); k++) {
+                    unsigned_tx &u = unsig[k];
+                    if (u.rp_len != proof_bytes) { failed = 1; return; }
+                    memcpy(&u.preimage[u.rp_off], &g_proofs[proof_bytes * k], proof_bytes);
+                    drbg rng(seeds[k].data()); rng.ctr = sign_ctr[k];
+                    recs[k] = u.sign(senders[k % n_senders], rng);
+                    u = unsigned_tx();
+                }
+            }
+        };
+        if (!failed) {
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(signer);
+            for (auto &th : pool) th.join();
+        }
+        lap("signatures");
+    }
     if (failed) { delete S; return nullptr; }
     S->offsets.push_back(0);
-    for (u64 k = 0; k < n_txs; k++) { S->records.insert(S->records.end(), recs[k].begin(), recs[k].end()); S->offsets.push_back(S->records.size()); }
+    {
+        size_t total = 0;
+        for (auto &r : recs) total += r.size();
+        S->records.reserve(total);
+    }
+    for (u64 k = 0; k < n_txs; k++) { S->records.insert(S->records.end(), recs[k].begin(), recs[k].end()); S->offsets.push_back(S->records.size()); std::vector<u8>().swap(recs[k]); }
     xhe_ledger_view &v = S->view;
     memset(&v, 0, sizeof v);
     v.n_accounts = 2ull * n_senders; v.account_keys = S->account_keys.data(); v.account_nonces = S->nonces.data();
     v.n_balances = 2ull * n_senders; v.balance_account = S->balance_account.data(); v.balance_assets = S->balance_assets.data(); v.balance_cts = S->balance_cts.data();
     return S;
+}
+xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_senders, const uint8_t seed32[32], int32_t threads) {
+    return xhe_synth_transfers_gpu(nullptr, n_txs, n_transfers, n_senders, seed32, threads);
 }
 // n_groups groups of 16 transactions over disjoint account sets: two multisig set-ups (2 signers, threshold 2), four
 // one-transfer transactions, four with a native and a second-asset transfer (two source commitments, four value

@@ -263,6 +263,21 @@ __device__ __forceinline__ void prf_scalar_pair(sc &first, sc &second, const u32
     second = sc_from_wide_words(w);
 }
 
+// a point from the lane `delta` above (wavefront shuffle of its 40 limbs) and a branch-free choice between two points
+__device__ __forceinline__ ge ge_shfl_down(const ge &p, u32 delta) {
+    ge r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        r.X.v[i] = __shfl_down(p.X.v[i], delta, 64); r.Y.v[i] = __shfl_down(p.Y.v[i], delta, 64);
+        r.Z.v[i] = __shfl_down(p.Z.v[i], delta, 64); r.T.v[i] = __shfl_down(p.T.v[i], delta, 64);
+    }
+    return r;
+}
+__device__ __forceinline__ ge ge_select(const ge &a, const ge &b, bool flag) {
+    ge r; r.X = fe_select(a.X, b.X, flag); r.Y = fe_select(a.Y, b.Y, flag); r.Z = fe_select(a.Z, b.Z, flag); r.T = fe_select(a.T, b.T, flag);
+    return r;
+}
+
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace xhe

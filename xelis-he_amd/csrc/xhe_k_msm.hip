@@ -398,21 +398,6 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
     }
 }
 
-__device__ __forceinline__ ge ge_shfl_down(const ge &p, u32 delta) {
-    ge r;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        r.X.v[i] = __shfl_down(p.X.v[i], delta, 64); r.Y.v[i] = __shfl_down(p.Y.v[i], delta, 64);
-        r.Z.v[i] = __shfl_down(p.Z.v[i], delta, 64); r.T.v[i] = __shfl_down(p.T.v[i], delta, 64);
-    }
-    return r;
-}
-__device__ __forceinline__ ge ge_select(const ge &a, const ge &b, bool flag) {
-    ge r; r.X = fe_select(a.X, b.X, flag); r.Y = fe_select(a.Y, b.Y, flag); r.Z = fe_select(a.Z, b.Z, flag); r.T = fe_select(a.T, b.T, flag);
-    return r;
-}
-
-
 // Thread per chunk [t*M, (t+1)*M) of the bucket-sorted entries.  term_point (nullable): term index ->
 // record index in niels[]; n_points bounds the gather.  chunk_sums[2t] = partial sum of the bucket that
 // began before the chunk, chunk_sums[2t+1] = partial sum of the bucket that continues after it.

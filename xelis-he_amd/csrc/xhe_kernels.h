@@ -102,4 +102,26 @@ void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc);
 void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point);
 
+
+// ---- batched range-proof generation (xhe_k_prover.hip): inputs of the verification path, not part of it ----
+struct rp_dims { u32 n_txs, m, nm, lg, table_cap; };      // proofs in the chunk, values per proof, 64 m, log2(64 m), generators per side in gen_tab
+static constexpr u32 RP_TSTATE_WORDS = 52;                // transcript: 25 x u64 state, then pos | pos_begin << 8, padding
+// Montgomery-limb scalars kept per proof between the stages (9 words each)
+enum : u32 { RPS_Y = 0, RPS_Z, RPS_YINV, RPS_X, RPS_W, RPS_T0, RPS_T1, RPS_T2, RPS_CL, RPS_CR, RPS_U = 10, RPS_UINV = 26, RPS_COUNT = 42 };
+struct rp_buffers {
+    const u32 *seeds;        // n x 8: seed of the proof's random generator
+    const u64 *ctr0;         // n: its counter at the start of the proof
+    const u64 *values;       // n x m
+    const u32 *openings;     // n x m x 8: canonical scalars
+    u32 *tstate;             // n x RP_TSTATE_WORDS: transcript after the value commitments, updated stage by stage
+    u32 *sc_store;           // n x RPS_COUNT x 9
+    u32 *vec_a, *vec_b, *vec_yinv;   // n x nm x 9
+    u32 *part_a, *part_s;    // n x range_proof_as_segments(nm) XYZT records
+    u32 *part_lr;            // n x 2 x range_proof_lr_slots(nm) XYZT records
+    u32 *proofs;             // n x 8 (9 + 2 lg) words
+};
+u32 range_proof_lr_slots(u32 nm);
+u32 range_proof_as_segments(u32 nm);
+void launch_range_proofs(hipStream_t st, const rp_dims &d, const u32 *gen_tab, const rp_buffers &b);
+
 }  // namespace xhe
