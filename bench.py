@@ -2,8 +2,12 @@
 """Benchmark of the hot path: Transaction::verify_batch on MI355X.
 
 A step is one verification of one synthetic batch that is already resident in HBM
-(xhe_batch_upload once, then xhe_batch_verify per step).  The workload is BASELINE.json's configs[1]:
-a 10 000-transaction batch, 1 transfer each, single (native) asset, per GPU.  With --gpus N every rank
+(xhe_batch_upload once, then xhe_batch_verify per step).  The workload is BASELINE.json's configs[2], the
+largest single-GPU configuration: a 100 000-transaction batch, 8 transfers each (aggregated 64-bit range
+proofs over 16 value commitments), single (native) asset, per GPU; its 100 000 range proofs are generated
+on the GPU before the timed region (xhe_synth_transfers_gpu).  configs[1] (10 000 transactions, 1 transfer
+each) is measured after the timed region and reported as `secondary`; `end_to_end` is xhe_verify_batch from
+host buffers (parsing, ledger-key resolution and the host-to-device copy included).  With --gpus N every rank
 verifies its own batch (transactions shard by account group, no data-path collective) and the ranks
 AND-reduce their accept bits with one RCCL all-reduce (MIN) per step; value = transactions of all ranks
 / max-over-ranks time (weak scaling).
@@ -33,8 +37,8 @@ def measured_traffic(txs, transfers):
     import glob
     total, found = 0.0, 0
     for counter in ("fetch_size", "write_size"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%dtx.csv" % (counter, txs))))
-        if not files or transfers != 1:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%dtx%s.csv" % (counter, txs, "" if transfers == 1 else "_t%d" % transfers))))
+        if not files:
             return None
         with open(files[-1]) as f:
             for row in csv.DictReader(f):
@@ -49,8 +53,8 @@ def measured_valu_instructions(txs, transfers):
     pass of this very workload; None when no matching summary is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_%dtx.csv" % txs)))
-    if not files or transfers != 1:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_%dtx%s.csv" % (txs, "" if transfers == 1 else "_t%d" % transfers))))
+    if not files:
         return None
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
@@ -64,8 +68,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--txs", type=int, default=10000, help="transactions per GPU batch")
-    ap.add_argument("--transfers", type=int, default=1)
+    ap.add_argument("--txs", type=int, default=100000, help="transactions per GPU batch")
+    ap.add_argument("--transfers", type=int, default=8)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 10 000 x 1-transfer measurement after the timed region")
+    ap.add_argument("--e2e-reps", type=int, default=3, help="xhe_verify_batch calls from host buffers after the timed region (0 = skip)")
     ap.add_argument("--workload", choices=["transfers", "mixed"], default="transfers",
                     help="mixed: groups of 16 transactions (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers)")
     ap.add_argument("--senders", type=int, default=1024, help="sender accounts per batch (1 = the reference bench's single chain)")
@@ -75,6 +81,47 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo reduces through host memory, for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (only with --backend gloo)")
     return ap.parse_args()
+
+
+def term_counts(txs, transfers, mixed):
+    """MSM terms of one verification: dynamic terms (sigma proofs, range proofs, value commitments) and static generators."""
+    T, A = transfers, 1
+    m = 1
+    while m < A + T:
+        m *= 2
+    lg = 6 + (m.bit_length() - 1)
+    dyn_terms = txs * (7 * A + 8 * T + 4 + 2 * lg + A + T)
+    static_terms = 2 + 2 * 64 * m
+    if mixed:
+        # per group of 16: 2 set-ups (24 terms), 4 one-asset transfers (35), 4 two-asset double transfers (54), 2 native burns (24),
+        # 2 second-asset burns (34), 2 co-signed transfers (35); four value commitments at most -> 256 generators per side
+        dyn_terms = (txs // 16) * (2 * 24 + 4 * 35 + 4 * 54 + 2 * 24 + 2 * 34 + 2 * 35)
+        static_terms = 2 + 2 * 256
+    return dyn_terms, static_terms
+
+
+class Resident:
+    """One synthetic batch parsed and uploaded once (xhe_batch_upload); step() = xhe_batch_verify on it."""
+
+    def __init__(self, engine, lib, batch):
+        from xelis_he_amd.api import Verdict
+        self.engine, self.lib, self.batch = engine, lib, batch
+        self.handle = ctypes.c_void_p()
+        sv = Verdict()
+        t0 = time.time()
+        engine._check(lib.xhe_batch_upload(ctypes.c_void_p(engine.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view,
+                                           ctypes.byref(self.handle), ctypes.byref(sv)))
+        self.upload_s = time.time() - t0
+        assert sv.accept == 1, "synthetic batch is malformed"
+        self.verdict = Verdict()
+
+    def step(self, i):
+        seed = (i + 1).to_bytes(8, "little") * 4
+        self.engine._check(self.lib.xhe_batch_verify(ctypes.c_void_p(self.engine.ctx), self.handle, ctypes.byref(self.verdict), seed))
+        return self.verdict.accept
+
+    def free(self):
+        self.lib.xhe_batch_free(ctypes.c_void_p(self.engine.ctx), self.handle)
 
 
 def main():
@@ -104,7 +151,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     import xelis_he_amd
-    from xelis_he_amd.api import SyntheticBatch, Verdict, _lib
+    from xelis_he_amd.api import LedgerOut, SyntheticBatch, Verdict, _lib
     lib = _lib()
     lib.xhe_batch_upload.restype = ctypes.c_int32
     lib.xhe_batch_verify.restype = ctypes.c_int32
@@ -115,26 +162,16 @@ def main():
     mixed = args.workload == "mixed"
     if mixed:
         args.txs -= args.txs % 16
-    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed,
-                           engine=None if (mixed or args.cpu_prover) else engine)
+    gen_engine = None if (mixed or args.cpu_prover) else engine
+    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed, engine=gen_engine)
     gen_s = time.time() - t0
+    res = Resident(engine, lib, batch)
 
-    handle = ctypes.c_void_p()
-    sv = Verdict()
-    t0 = time.time()
-    engine._check(lib.xhe_batch_upload(ctypes.c_void_p(engine.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view,
-                                       ctypes.byref(handle), ctypes.byref(sv)))
-    upload_s = time.time() - t0
-    assert sv.accept == 1, "synthetic batch is malformed"
-
-    verdict = Verdict()
     on_host = args.backend != "nccl"              # gloo gets host tensors only
     flag = torch.ones(1, dtype=torch.int64, device="cpu" if (on_host or dist is None) else "cuda")
 
     def step(i):
-        seed = (i + 1).to_bytes(8, "little") * 4
-        engine._check(lib.xhe_batch_verify(ctypes.c_void_p(engine.ctx), handle, ctypes.byref(verdict), seed))
-        ok = verdict.accept
+        ok = res.step(i)
         if dist is not None:
             flag.fill_(ok)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # AND of the per-shard accept bits
@@ -174,37 +211,37 @@ def main():
             detail[name] = detail.get(name, 0.0) + ms / reps
     # algorithmic bytes of the multiscalar check: per dynamic term a 32-byte scalar + a 128-byte decoded
     # point record, per static generator the same, 32 bytes of result
-    T, A = args.transfers, 1
-    m = 1
-    while m < A + T:
-        m *= 2
-    lg = 6 + (m.bit_length() - 1)
-    dyn_terms = args.txs * (7 * A + 8 * T + 4 + 2 * lg + A + T)
-    static_terms = 2 + 2 * 64 * m
-    if mixed:
-        # per group of 16: 2 set-ups (24 terms), 4 one-asset transfers (35), 4 two-asset double transfers (54), 2 native burns (24),
-        # 2 second-asset burns (34), 2 co-signed transfers (35); four value commitments at most -> 256 generators per side
-        dyn_terms = (args.txs // 16) * (2 * 24 + 4 * 35 + 4 * 54 + 2 * 24 + 2 * 34 + 2 * 35)
-        static_terms = 2 + 2 * 256
+    dyn_terms, static_terms = term_counts(args.txs, args.transfers, mixed)
     algo_bytes = (dyn_terms + static_terms) * 160 + 32
     acc_ms = stages.get("msm_accumulate", 0.0)
     roofline = None
     if acc_ms > 0:
         achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                    "traffic": measured_traffic(args.txs, args.transfers), "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": algo_bytes}
+                    "traffic": None if mixed else measured_traffic(args.txs, args.transfers), "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4),
+                    "algorithmic_bytes": algo_bytes, "terms": dyn_terms + static_terms}
 
-    # The kernel is bound by VALU issue, not by HBM: wave-instructions per launch (PMC) / launch time against one
-    # wave-instruction per 4 cycles per SIMD (a 64-wide wavefront on a 16-lane SIMD), the chip's upper bound for 32-bit VALU work.
+    # The kernel is bound by VALU issue, not by HBM: wave-instructions per launch (PMC) / launch time against the chip's vector
+    # issue rate, one wave-instruction per 2 cycles per SIMD (a 64-wide wavefront on a SIMD-32 takes two passes).  The kernel's
+    # mix is mostly v_mad_u64_u32, which issues in 5.5 cycles (tools/ubench_valu.hip, 8 waves per SIMD): `mix_bound_frac` prices
+    # the measured instruction count at the mix-weighted cost of profiles/r02_accumulate_mix.json when that file is committed.
     valu = None
     n_valu = measured_valu_instructions(args.txs, args.transfers) if not mixed else None
     if n_valu and acc_ms > 0:
         prop = torch.cuda.get_device_properties(local_rank)
         clock_hz = getattr(prop, "clock_rate", 2400000) * 1e3
-        peak = prop.multi_processor_count * 4 * clock_hz / 4.0
+        simds = prop.multi_processor_count * 4
+        peak = simds * clock_hz / 2.0
         rate = n_valu / (acc_ms * 1e-3)
         valu = {"kernel": "k_msm_accumulate", "wave_instructions": int(n_valu), "achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2),
-                "unit": "G wave-instructions/s", "frac": round(rate / peak, 4), "simds": prop.multi_processor_count * 4, "clock_mhz": round(clock_hz / 1e6)}
+                "unit": "G wave-instructions/s", "frac": round(rate / peak, 4), "cycles_per_wave_instruction_at_peak": 2, "simds": simds, "clock_mhz": round(clock_hz / 1e6)}
+        mix_path = os.path.join(ROOT, "profiles", "r02_accumulate_mix.json")
+        if os.path.exists(mix_path):
+            with open(mix_path) as f:
+                mix = json.load(f)
+            cyc = float(mix["cycles_per_wave_instruction"])
+            valu["mix_cycles_per_wave_instruction"] = cyc
+            valu["mix_bound_frac"] = round(rate / (simds * clock_hz / cyc), 4)
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
@@ -219,7 +256,52 @@ def main():
             one = oracle.xo_bench_verify_batch(batch.records, batch.offsets, ctypes.c_uint64(min(n_s, 256)), batch.view, 1, ctypes.byref(ok))
             cpu_baseline = {"value": round(cores * n_s / sec, 1), "unit": "tx/s", "cores": cores, "kind": "port",
                             "sample": "first %d transactions of the batch, one ledger clone per thread, %d threads (benches/tx.rs:307-325 style)" % (n_s, cores),
-                            "single_thread_ms_per_tx": round(one / min(n_s, 256) * 1e3, 4), "reference_published_ms_per_tx": 0.40}
+                            "single_thread_ms_per_tx": round(one / min(n_s, 256) * 1e3, 4), "reference_published_ms_per_tx_1_transfer": 0.40}
+
+    # after the timed region, rank 0 at N = 1: the drop-in call from host buffers, and BASELINE's 10 000 x 1-transfer configuration
+    end_to_end, secondary = None, None
+    if rank == 0 and args.gpus == 1:
+        engine.set_stage_timing(0)
+        if args.e2e_reps > 0:
+            lib.xhe_verify_batch.restype = ctypes.c_int32
+            view = batch.view.contents
+            out_cts = (ctypes.c_uint8 * max(64 * view.n_balances, 1))()
+            out_nonces = (ctypes.c_uint64 * max(view.n_accounts, 1))()
+            ms_set = (ctypes.c_int64 * max(view.n_accounts, 1))()
+            out = LedgerOut(out_cts, out_nonces, ms_set)
+            v = Verdict()
+            times = []
+            for i in range(args.e2e_reps + 1):
+                t0 = time.perf_counter()
+                engine._check(lib.xhe_verify_batch(ctypes.c_void_p(engine.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view, ctypes.byref(out),
+                                                   ctypes.byref(v), (1000 + i).to_bytes(8, "little") * 4))
+                times.append(time.perf_counter() - t0)
+                assert v.accept == 1
+            best = min(times[1:])
+            end_to_end = {"call": "xhe_verify_batch from host buffers (parse + ledger keys + H2D + verify + ledger read-back)", "ms_per_batch": round(best * 1e3, 3),
+                          "value": round(batch.n_txs / best, 1), "unit": "tx/s", "record_bytes": len(batch.records), "reps": args.e2e_reps}
+        if not args.no_secondary and not mixed and (args.txs, args.transfers) != (10000, 1):
+            t0 = time.time()
+            b2 = SyntheticBatch(10000, 1, 1024, seed=b"bench-secondary", threads=args.gen_threads, engine=gen_engine)
+            g2 = time.time() - t0
+            engine.set_stage_timing(1)
+            r2 = Resident(engine, lib, b2)
+            for i in range(10):
+                assert r2.step(i) == 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            acc2 = 0.0
+            for i in range(50):
+                assert r2.step(10 + i) == 1
+                acc2 += dict(engine.stage_times()).get("msm_accumulate", 0.0)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t0
+            d2, s2 = term_counts(10000, 1, False)
+            secondary = {"workload": "10000-tx batch, 1 transfer each, single asset, 1024 sender accounts", "ms_per_step": round(e2 / 50 * 1e3, 4), "value": round(10000 * 50 / e2, 1),
+                         "unit": "tx/s", "steps": 50, "warmup": 10, "msm_accumulate_ms": round(acc2 / 50, 4),
+                         "roofline_frac": round(((d2 + s2) * 160 + 32) / (acc2 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if acc2 > 0 else None, "generate_s": round(g2, 2)}
+            r2.free()
+            b2.close()
 
     if rank == 0:
         total_txs = args.txs * args.gpus * args.steps
@@ -229,14 +311,15 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": ("%d-tx mixed batch per GPU (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers), %d account groups" % (args.txs, args.txs // 16)) if mixed
                        else "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
-                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus},
-            "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline,
+                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus,
+                       "inputs": "resident in HBM (xhe_batch_upload before the timed region); see end_to_end for the call from host buffers"},
+            "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline, "end_to_end": end_to_end, "secondary": secondary,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stage_detail_ms": {k: round(v, 4) for k, v in detail.items()},
-            "setup": {"generate_s": round(gen_s, 2), "parse_upload_s": round(upload_s, 4)},
+            "setup": {"generate_s": round(gen_s, 2), "range_proofs": "cpu" if gen_engine is None else "gpu", "parse_upload_s": round(res.upload_s, 4)},
         }
         print(json.dumps(out), flush=True)
-    lib.xhe_batch_free(ctypes.c_void_p(engine.ctx), handle)
+    res.free()
     engine.close()
     if dist is not None:
         dist.destroy_process_group()

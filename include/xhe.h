@@ -154,6 +154,18 @@ int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *batch, const xhe_ledger_o
 int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *batch, xhe_verdict *verdict);
 void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
 
+/* Diagnostics for parity tests (no counterpart in the reference): internal values of an uploaded batch.
+ *   XHE_DEBUG_CHALLENGES  after xhe_batch_verify: the Fiat-Shamir challenges of every transaction in transaction order, as
+ *                         ProtocolTranscript::challenge_scalar yields them (src/transcript.rs:46-51): per source commitment
+ *                         c, w; per transfer c, w; then the range proof's y, z, x, w, u_1..u_lg.  32 bytes each.
+ *   XHE_DEBUG_GENERATORS  B, B_blinding (= H), then the first k generators G_i and the first k H_i of BP_GENS
+ *                         (src/proofs.rs:19-22) as the kernels hold them, re-encoded: 32 bytes each, k = (cap / 32 - 2) / 2
+ *                         capped at the batch's generator count.
+ * Returns the number of 32-byte values written, or < 0. */
+#define XHE_DEBUG_CHALLENGES 1
+#define XHE_DEBUG_GENERATORS 2
+int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *batch, int32_t what, uint8_t *out, uint64_t cap_bytes);
+
 /* Per-stage GPU time of the last xhe_batch_verify / xhe_msm_vartime on this context, measured with HIP
  * events on the stream each stage runs on (stages on different streams overlap; "total" spans the main
  * stream).  names/ms arrays of length cap; returns the number of stages. */

@@ -14,6 +14,7 @@
 #include "xhe_ingest.h"
 #include "xhe_kernels.h"
 #include "xhe_ctx.h"
+#include "xhe_ge.h"
 
 using namespace xhe;
 
@@ -493,6 +494,39 @@ int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *B, const xhe_ledger_out *
     if (out->account_nonces) memcpy(out->account_nonces, B->in_nonces.data(), 8 * B->n_accounts);
     if (out->multisig_set_by) memcpy(out->multisig_set_by, hb.multisig_set_by.data(), 8 * B->n_accounts);
     return 0;
+}
+
+// Diagnostics for parity tests: internal values of an uploaded batch, copied out after xhe_batch_verify.
+int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *B, int32_t what, uint8_t *out, uint64_t cap_bytes) {
+    if (!ctx || !B || !out) return XHE_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const host_batch &hb = B->hb;
+    if (!hb.structural.accept || !B->pts.p) { set_error(ctx, "xhe_batch_debug_read: the batch was not uploaded to the device"); return XHE_E_ARG; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (what == XHE_DEBUG_CHALLENGES) {
+        const u64 n = std::min<u64>(hb.n_chal, cap_bytes / 32);
+        if (n) HIPCHK(ctx, hipMemcpy(out, B->chal.p, 32 * n, hipMemcpyDeviceToHost));
+        return (int64_t)n;
+    }
+    if (what == XHE_DEBUG_GENERATORS) {
+        // B, H, then G_vec[0..k) and H_vec[0..k) of the batch's point array (affine Niels records), re-encoded on the host
+        const u64 k = std::min<u64>(hb.nm_cap, cap_bytes / 32 >= 2 ? (cap_bytes / 32 - 2) / 2 : 0);
+        if (cap_bytes < 64) return XHE_E_ARG;
+        std::vector<u32> rec(32 * (2 + 2 * k));
+        HIPCHK(ctx, hipMemcpy(rec.data(), B->pts.p, 128 * (2 + k), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(ctx, hipMemcpy(rec.data() + 32 * (2 + k), B->pts.as<u8>() + 128ull * (2 + hb.nm_cap), 128 * k, hipMemcpyDeviceToHost));
+        fe inv2 = fe_zero();                                // (p + 1) / 2
+        inv2.v[0] = (1u << 26) - 9;
+        for (int i = 1; i < 9; i++) inv2.v[i] = (i & 1) ? FE_MASK25 : FE_MASK26;
+        inv2.v[9] = (1u << 24) - 1;
+        for (u64 i = 0; i < 2 + 2 * k; i++) {
+            ge_niels q = ge_niels_load(rec.data() + 32 * i);
+            ge p; p.X = fe_mul(fe_sub(q.ypx, q.ymx), inv2); p.Y = fe_mul(fe_add(q.ypx, q.ymx), inv2); p.Z = fe_one(); p.T = fe_mul(p.X, p.Y);
+            ristretto_encode(out + 32 * i, p);
+        }
+        return (int64_t)(2 + 2 * k);
+    }
+    return XHE_E_ARG;
 }
 
 int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, const xhe_ledger_out *out,
