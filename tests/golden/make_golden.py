@@ -32,8 +32,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers  # noqa: E402
 from oracle import spec_ristretto as S  # noqa: E402
 from xelis_he_amd import codes  # noqa: E402
-from xelis_he_amd.api import (NATIVE, Account, Ledger, LedgerOut, Transaction, TransactionBuilder, TransferBuilder,  # noqa: E402
-                              Verdict)
+from xelis_he_amd.api import (NATIVE, Account, Ledger, LedgerOut, Transaction, TransactionBuilder, TransactionUnsigned,  # noqa: E402
+                              TransferBuilder, Verdict)
 
 ASSET55 = bytes([55]) * 32
 BASEPOINT = "e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"
@@ -212,6 +212,46 @@ def tx_cases(oracle):
     ms_missing.set_multisig_for_account(alice.pubkey, [s1.pubkey], 1)
     cases.append(run_case(oracle, "reject_multisig_required", [t1], ms_missing))
     cases.append(run_case(oracle, "empty_batch", [], Ledger([alice, bob])))
+
+    # lying provers: the record is edited before it is signed, so the signature is valid and the proof's own error variant shows
+    # (proofs.rs:151-179,293-317): Transcript(IdentityPoint), CommitmentEqProof, CiphertextValidityProof
+    def resigned(unsigned, keypair, edits, seed):
+        r = bytearray(unsigned.record)
+        for off, data in edits:
+            r[off:off + len(data)] = data
+        return TransactionUnsigned(bytes(r)).sign(keypair, seed)
+    kim, lee = Account([(NATIVE, 100)], "g-kim"), Account([(NATIVE, 0)], "g-lee")
+    ku = TransactionBuilder(1, kim.pubkey, ("transfers", [TransferBuilder(lee.pubkey, 10)]), 1, 0).build_unsigned({NATIVE: 100}, kim.keypair, "g-ku", kim)
+    cm, xf_proof, bad_point = len(ku.record) - 64 - 256, 16 + 4 + 49 + 160, bytes([255]) * 32
+    kl = Ledger([kim, lee])
+    cases.append(run_case(oracle, "reject_identity_in_eq_proof", [resigned(ku, kim.keypair, [(cm + 64, bytes(32))], "g-k1")], kl))
+    cases.append(run_case(oracle, "reject_identity_in_validity_proof", [resigned(ku, kim.keypair, [(xf_proof + 32, bytes(32))], "g-k2")], kl))
+    cases.append(run_case(oracle, "reject_undecodable_eq_proof_point", [resigned(ku, kim.keypair, [(cm + 64 + 32, bad_point)], "g-k3")], kl))
+    cases.append(run_case(oracle, "reject_undecodable_validity_proof_point", [resigned(ku, kim.keypair, [(xf_proof + 64, bad_point)], "g-k4")], kl))
+    # a range proof with one inner-product round too many (verify.rs:504-514 -> RangeProof)
+    rec = bytearray(ku.record)
+    rp_len = int.from_bytes(rec[12:14], "little")
+    tail = 16 + 4 + 49 + 320 + rp_len - 64
+    rec[tail:tail] = bytes(rec[tail - 64:tail])
+    rec[12:14] = (rp_len + 64).to_bytes(2, "little")
+    cases.append(run_case(oracle, "reject_range_proof_rounds", [TransactionUnsigned(bytes(rec)).sign(kim.keypair, "g-k5")], kl))
+    # multisig: an entry whose signer index is beyond the configuration is skipped (verify.rs:276)
+    mu = TransactionBuilder(1, kim.pubkey, ("transfers", [TransferBuilder(lee.pubkey, 10)]), 1, 0).build_unsigned({NATIVE: 100}, kim.keypair, "g-mu", kim)
+    mu.set_multisig([(0, s1.keypair.sign(mu.hash(), "g-m0")), (7, s2.keypair.sign(b"unchecked", "g-m7"))])
+    ml = Ledger([kim, lee, s1])
+    ml.set_multisig_for_account(kim.pubkey, [s1.pubkey], 2)
+    cases.append(run_case(oracle, "multisig_index_out_of_range_skipped", [mu.sign(kim.keypair, "g-mf")], ml))
+    # extra data, contract call with deposits, contract deployment
+    ex = TransactionBuilder(1, kim.pubkey, ("transfers", [TransferBuilder(lee.pubkey, 3, NATIVE, b"golden memo"), TransferBuilder(lee.pubkey, 4)]), 2, 0).build(
+        {NATIVE: 100}, kim.keypair, "g-extra", kim)
+    cases.append(run_case(oracle, "transfer_with_extra_data", [ex], kl))
+    moe = Account([(NATIVE, 500), (ASSET55, 40)], "g-moe")
+    call = TransactionBuilder(1, moe.pubkey, ("call_contract", bytes([7]) * 32, [(NATIVE, 20), (ASSET55, 15)], b"params"), 5, 0).build(
+        {NATIVE: 500, ASSET55: 40}, moe.keypair, "g-call", moe)
+    after = Ledger([moe]).clone()
+    call.apply_without_verify(after)
+    deploy = TransactionBuilder(1, moe.pubkey, ("deploy_contract", b"golden module" * 9), 7, 0).build({NATIVE: 475}, moe.keypair, "g-deploy", after.get_account(moe.pubkey))
+    cases.append(run_case(oracle, "contract_call_then_deploy", [call, deploy], Ledger([moe])))
     return cases
 
 

@@ -130,8 +130,12 @@ def test_transcript_template_matches_transcript(oracle, hostlib):
             out = buf(32 * 64)
             blocks, zeros = ctypes.c_uint32(), ctypes.c_uint32()
             n = hostlib.xt_transcript_template_challenges(rec, ctypes.c_uint64(len(rec)), out, ctypes.c_uint64(64), ctypes.byref(blocks), ctypes.byref(zeros))
+            if case["name"] == "reject_range_proof_rounds":
+                assert n < 0, "a proof length that disagrees with the value count has no template (the serial transcript handles it)"
+                continue
             assert n * 64 == len(want) and bytes(out)[:32 * n].hex() == want, case["name"]
-            assert zeros.value == 0 and blocks.value > 10
+            # the all-zero encodings a template reports are the ones validate_and_append_point rejects
+            assert zeros.value == (1 if "identity_in" in case["name"] else 0) and blocks.value > 10, case["name"]
             seen += 1
     assert seen >= 15
 

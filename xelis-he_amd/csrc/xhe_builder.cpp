@@ -76,10 +76,16 @@ static void ct_validity_prove(std::vector<u8> &out, const ge &dest_pub, const ge
 }
 
 // ---- aggregated range proof (dalek-bulletproofs prove_multiple, party/dealer folded into one pass) ---
+// Sums stay lazy for a few terms only: a scalar holds values below 2^257 (xhe_sc.h), a product is below 1.07 l, so every eighth
+// addition the running sum is brought back below 1.07 l (a Montgomery product with one).
+static inline sc sc_reduce(const sc &x) { return sc_mul(x, sc_one()); }
 static sc inner(const std::vector<sc> &a, const std::vector<sc> &b, size_t off_a, size_t off_b, size_t n) {
     sc acc = sc_zero();
-    for (size_t i = 0; i < n; i++) acc = sc_add(acc, sc_mul(a[off_a + i], b[off_b + i]));
-    return acc;
+    for (size_t i = 0; i < n; i++) {
+        acc = sc_add(acc, sc_mul(a[off_a + i], b[off_b + i]));
+        if ((i & 7) == 7) acc = sc_reduce(acc);
+    }
+    return sc_reduce(acc);
 }
 
 void range_proof_begin(transcript &t, const std::vector<u64> &values, const std::vector<sc> &openings) {
@@ -131,15 +137,18 @@ void range_proof_prove(std::vector<u8> &out, transcript &t, const std::vector<u6
             r1[i] = sc_mul(exp_y, s_R[i]);
             exp_y = sc_mul(exp_y, y); exp_2 = sc_mul(exp_2, two);
         }
-        t0_blinding = sc_add(t0_blinding, sc_mul(offset_zz, openings[j]));
+        t0_blinding = sc_reduce(sc_add(t0_blinding, sc_mul(offset_zz, openings[j])));
         exp_z = sc_mul(exp_z, z);
     }
     sc t0 = inner(l0, r0, 0, 0, nm), t2 = inner(l1, r1, 0, 0, nm);
     sc t1;
     {
         sc acc = sc_zero();
-        for (size_t i = 0; i < nm; i++) acc = sc_add(acc, sc_mul(sc_add(l0[i], l1[i]), sc_add(r0[i], r1[i])));
-        t1 = sc_sub(sc_sub(acc, t0), t2);
+        for (size_t i = 0; i < nm; i++) {
+            acc = sc_add(acc, sc_mul(sc_add(l0[i], l1[i]), sc_add(r0[i], r1[i])));
+            if ((i & 7) == 7) acc = sc_reduce(acc);
+        }
+        t1 = sc_sub(sc_sub(sc_reduce(acc), t0), t2);
     }
     sc t1_blinding = rng.scalar(), t2_blinding = rng.scalar();
     ge T1 = ge_add(mul_G(t1), mul_H(t1_blinding)), T2 = ge_add(mul_G(t2), mul_H(t2_blinding));
