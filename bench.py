@@ -280,6 +280,24 @@ def main():
             best = min(times[1:])
             end_to_end = {"call": "xhe_verify_batch from host buffers (parse + ledger keys + H2D + verify + ledger read-back)", "ms_per_batch": round(best * 1e3, 3),
                           "value": round(batch.n_txs / best, 1), "unit": "tx/s", "record_bytes": len(batch.records), "reps": args.e2e_reps}
+            # the same call over a run of batches, pipelined inside the library (upload of batch k + 1 beside the verification of batch k)
+            class BatchArgs(ctypes.Structure):
+                _fields_ = [("records", ctypes.c_char_p), ("offsets", ctypes.POINTER(ctypes.c_uint64)), ("n_txs", ctypes.c_uint64), ("view", ctypes.c_void_p),
+                            ("out", ctypes.c_void_p), ("seed", ctypes.c_char_p)]
+            n_b = 6
+            arr = (BatchArgs * n_b)()
+            seeds = [(2000 + i).to_bytes(8, "little") * 4 for i in range(n_b)]
+            for i in range(n_b):
+                arr[i].records, arr[i].offsets, arr[i].n_txs = batch.records, batch.offsets, batch.n_txs
+                arr[i].view, arr[i].out, arr[i].seed = ctypes.cast(batch.view, ctypes.c_void_p), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p), seeds[i]
+            vs = (Verdict * n_b)()
+            lib.xhe_verify_batches.restype = ctypes.c_int32
+            t0 = time.perf_counter()
+            engine._check(lib.xhe_verify_batches(ctypes.c_void_p(engine.ctx), ctypes.c_uint64(n_b), arr, vs))
+            dt = time.perf_counter() - t0
+            assert all(v_.accept == 1 for v_ in vs)
+            end_to_end["pipelined"] = {"call": "xhe_verify_batches over %d such batches from host buffers" % n_b, "ms_per_batch": round(dt / n_b * 1e3, 3),
+                                       "value": round(n_b * batch.n_txs / dt, 1), "unit": "tx/s"}
         if not args.no_secondary and not mixed and (args.txs, args.transfers) != (10000, 1):
             t0 = time.time()
             b2 = SyntheticBatch(10000, 1, 1024, seed=b"bench-secondary", threads=args.gen_threads, engine=gen_engine)

@@ -5,9 +5,10 @@
  * all multi-byte integers in buffers are little-endian unless stated; all buffers are caller-owned
  * host memory unless the name says "_dev".  Return value: 0 = the call ran (the verdict is in the out
  * struct), < 0 = usage or runtime error (XHE_E_*).  A context is bound to one GPU (it owns four HIP streams
- * there, all at the default priority: with the default GPU_MAX_HW_QUEUES = 4 that is every hardware queue of the
- * process, so a caller's own stream shares a queue with one of them) and must not be used from two threads at once; different contexts
- * are independent.
+ * for kernels and one for the uploads' copies there, all at the default priority: with the default GPU_MAX_HW_QUEUES = 4 that is
+ * every hardware queue of the process, so a caller's own stream shares a queue with one of them) and must not be used from two threads at once, with one exception:
+ * xhe_batch_upload of one batch may run beside xhe_batch_verify / xhe_batch_apply / xhe_batch_read_ledger of another (that is what
+ * xhe_verify_batches does); different contexts are independent.
  */
 #ifndef XHE_H
 #define XHE_H
@@ -136,6 +137,17 @@ typedef struct xhe_verdict {
 int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
                          const xhe_ledger_view *in, const xhe_ledger_out *out, xhe_verdict *verdict,
                          const uint8_t rng_seed[32]);
+
+/* xhe_verify_batch over several independent batches (each against its own ledger snapshot, e.g. the blocks a node is catching up on),
+ * pipelined inside the library: a helper thread parses and uploads batch k + 1 while batch k is verified, so the host work and the
+ * host-to-device copy of one batch hide behind the GPU work of the one before.  verdicts[k] and batches[k].out are what
+ * xhe_verify_batch would give for batch k alone.  Returns the first call-level error (the batches behind it are not verified). */
+typedef struct xhe_batch_args {
+    const uint8_t *records; const uint64_t *offsets; uint64_t n_txs;
+    const xhe_ledger_view *in; const xhe_ledger_out *out;   /* out may be NULL */
+    const uint8_t *rng_seed;                                /* 32 bytes */
+} xhe_batch_args;
+int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_args *batches, xhe_verdict *verdicts);
 
 /* The same verification on a batch already resident in HBM: xhe_batch_upload parses, checks and
  * uploads the records and the ledger once; xhe_batch_verify runs only GPU work plus a 16-byte

@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 #include "../../include/xhe.h"
 #include "xhe_kernels.h"
+#include "xhe_ingest.h"
 
 namespace xhe {
 void set_error(xhe_ctx *ctx, const std::string &msg);
@@ -149,9 +151,15 @@ struct xhe_ctx {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};            // [0] ledger scan + static-generator scalars, [1] point decoding (+ signatures), [2] signatures of
                                                                   // large batches only; all at the default priority
     hipEvent_t ev_keys = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
-    std::string error;
+    hipStream_t copy_stream = nullptr;            // host-to-device copies of the uploads only (no kernels): an upload may run beside a verification
+    hipEvent_t ev_stage_free = nullptr;           // fires when the last copy out of the pinned staging memory has finished
+    std::string error; std::mutex err_mu;
+    // held shared by everything that reads the constant tables on the device (verification, apply, proving), exclusively while
+    // ensure_tables rebuilds them for a larger capacity
+    std::shared_mutex tables_mu;
     stage_timer timer;
     dev_pool pool;                 // blocks of freed batches
+    xhe::host_batch spare_host; std::mutex spare_mu;   // host tables of a freed batch, kept for their memory
     void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
     u32 *verdict_host = nullptr;                     // 64 pinned bytes the verdict words are read back into
     // level-0 workspace

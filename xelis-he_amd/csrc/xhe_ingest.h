@@ -3,15 +3,23 @@
 // /root/reference/src/tx/verify.rs:210-225,259-292,301-303,354-360,401-418) and lays out the flat tables
 // of xhe_verify_types.h for the kernels.  No group or field arithmetic happens here.
 //
-// Transactions are walked in order against a copy of the ledger's key structure (which accounts, which
-// (account, asset) slots, which multisig configurations exist); a MultiSig transaction updates the
-// configuration seen by the transactions after it, as in the reference's sequential pre_verify.  Each
-// transaction's checks assume the transactions before it passed: the verdict takes the failure of the
-// lowest transaction index, for which that assumption holds.
+// The work is split by what depends on the order of the transactions.  Parsing a record, looking its accounts and
+// (account, asset) slots up in the ledger and writing its descriptors depend on that record alone and run on all host
+// threads; between them one light sequential walk over the batch hands out everything the order decides: which
+// transaction touches an account key or a ledger slot first (its point is decoded once, the ledger scan starts from
+// it), the position of every ledger operation inside its slot's run, the multisig configuration a transaction sees (a
+// MultiSig transaction updates the configuration seen by the transactions after it, as in the reference's sequential
+// pre_verify), the distinct signing keys, the transcript templates.  Each transaction's checks assume the transactions
+// before it passed: the verdict takes the failure of the lowest transaction index, for which that assumption holds.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../include/xhe.h"
@@ -33,31 +41,49 @@ typedef byte_key<32> key32;
 typedef byte_key<36> key36;          // asset(32) || account index(4)
 static inline key32 make_key32(const u8 *p) { key32 k; memcpy(k.b, p, 32); return k; }
 
+// A growable array of plain data that is not cleared when it is sized (the ingest writes every element it sizes; clearing
+// hundreds of megabytes of descriptors first costs as much as writing them).
+template <typename T> struct pod_vec {
+    T *p = nullptr; size_t n = 0, cap = 0;
+    pod_vec() {}
+    pod_vec(const pod_vec &) = delete;
+    pod_vec &operator=(const pod_vec &) = delete;
+    ~pod_vec() { free(p); }
+    void reserve(size_t c) { if (c > cap) { p = (T *)realloc(p, c * sizeof(T)); cap = c; } }
+    void resize(size_t k) { reserve(k); n = k; }
+    void assign(size_t k, const T &v) { resize(k); for (size_t i = 0; i < k; i++) p[i] = v; }
+    void push_back(const T &v) { if (n == cap) reserve(cap ? 2 * cap : 64); p[n++] = v; }
+    T *data() { return p; } const T *data() const { return p; }
+    size_t size() const { return n; } bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+    T *begin() { return p; } T *end() { return p + n; } const T *begin() const { return p; } const T *end() const { return p + n; }
+    // takes the other array's memory when that is the larger one (the other keeps this one's); both end up empty
+    void trade_storage(pod_vec &o) { if (o.cap > cap) { std::swap(p, o.p); std::swap(cap, o.cap); } n = 0; o.n = 0; }
+};
+
 struct host_batch {
     u64 n_txs = 0;
     u64 bytes_len = 0, rec_bytes = 0, n_signer_keys = 0;      // device byte buffer: records || account keys || balance cts || multisig signers || spare
     u64 keys_base = 0, cts_base = 0, signers_base = 0;
-    std::vector<dev_tx> txs;
-    std::vector<dev_cm> cms;
-    std::vector<dev_xfer> xfers;
-    std::vector<dev_dec> decs;             // decode list; point index = n_static + position
-    std::vector<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
-    std::vector<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
-    std::vector<u32> bulk_decs;            // positions in decs[] of every other point
+    pod_vec<dev_tx> txs;
+    pod_vec<dev_cm> cms;
+    pod_vec<dev_xfer> xfers;
+    pod_vec<dev_dec> decs;             // decode list; point index = n_static + position: per-transaction blocks, then the shared points
+    pod_vec<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
+    pod_vec<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
+    pod_vec<u32> bulk_decs;            // positions in decs[] of every other point
     std::vector<u32> sig_keys;             // point index of every distinct key a signature of the batch is checked against
-    std::vector<dev_op> ops;               // sorted by slot
-    std::vector<dev_sig> sigs;
-    std::vector<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
-    std::vector<u32> apply_err;            // the subset apply_without_verify knows: unknown account / asset only
-    std::vector<u32> rp_dec_tx;            // per decode entry: tx whose range proof owns the point, 0xffffffff otherwise
+    pod_vec<dev_op> ops;               // sorted by slot
+    pod_vec<dev_sig> sigs;
+    pod_vec<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
+    pod_vec<u32> apply_err;            // the subset apply_without_verify knows: unknown account / asset only
     std::vector<u32> slot_of_used;         // used slot -> ledger balance index
     std::vector<u32> slot_last_op;         // used slot -> index of its last op in ops[]
-    std::vector<u32> slot_first_op;
     std::vector<u32> ms_hash_tx;           // transactions whose pre-image BLAKE3 digest is needed
     std::vector<std::vector<u32>> lg_groups;   // transactions by lg (index = lg)
     std::vector<int64_t> multisig_set_by;  // per account
     std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
-    std::vector<u32> segs;                 // per-transaction segment tables
+    pod_vec<u32> segs;                 // per-transaction segment tables
     std::vector<u32> serial_txs;           // transactions whose transcript runs in the serial kernel
     std::vector<u32> tr_list;              // the others, sorted by template, each template padded to whole tiles of 64 (0xffffffff)
     std::vector<transcript_tile> tr_tiles; // one per 64 entries of tr_list
@@ -67,43 +93,97 @@ struct host_batch {
     u32 emit_base = 0, n_emit = 0;         // emitted ciphertext points (2 per commitment)
     u32 n_chal = 0;
     u32 n_terms = 0, sigma_terms = 0, static_term_off = 0;
+    bool bad_ledger = false;               // the ledger view itself is inconsistent (indices out of range): a usage error, not a verdict
     xhe_verdict structural{1, XHE_OK, -1};
+    // The large tables are written once per batch and their memory is worth keeping: a freed batch leaves it to the next one
+    // (fresh pages cost a fault each, more than writing them).
+    void trade_storage(host_batch &o) {
+        txs.trade_storage(o.txs); cms.trade_storage(o.cms); xfers.trade_storage(o.xfers); decs.trade_storage(o.decs); early_decs.trade_storage(o.early_decs);
+        key_decs.trade_storage(o.key_decs); bulk_decs.trade_storage(o.bulk_decs); ops.trade_storage(o.ops); sigs.trade_storage(o.sigs); tx_err.trade_storage(o.tx_err);
+        apply_err.trade_storage(o.apply_err); segs.trade_storage(o.segs);
+    }
 };
 
-// returns false when a record is malformed (hb.structural says which)
-static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv) {
-    hb.n_txs = n;
-    std::vector<tx_record> recs(n);
-    u32 max_lg = 6;
-    for (u64 i = 0; i < n; i++) {
-        if (offsets[i + 1] < offsets[i] || !record_parse(recs[i], records + offsets[i], offsets[i + 1] - offsets[i])) {
-            hb.structural = {0, XHE_ERR_MALFORMED, (int64_t)i};
-            return false;
-        }
-        const tx_record &t = recs[i];
-        // a HashMap cannot hold one asset twice (src/tx/mod.rs:78)
-        if (t.type == 3)
-            for (u32 a = 0; a < t.n_items; a++)
-                for (u32 b = a + 1; b < t.n_items; b++)
-                    if (!memcmp(t.payload() + 32 + 40 * a, t.payload() + 32 + 40 * b, 32)) { hb.structural = {0, XHE_ERR_MALFORMED, (int64_t)i}; return false; }
-        if (t.lg() > max_lg) max_lg = t.lg();
+// fn(lo, hi) over [0, count) on up to `threads` host threads (the calling thread takes the first range)
+template <typename F>
+static inline void ingest_parallel(u64 count, unsigned threads, F fn) {
+    if (threads <= 1 || count < 2048) { if (count) fn((u64)0, count); return; }
+    const u64 per = (count + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) {
+        const u64 lo = t * per, hi = std::min(count, lo + per);
+        if (lo < hi) pool.emplace_back([=]() { fn(lo, hi); });
     }
+    fn((u64)0, std::min(count, per));
+    for (auto &th : pool) th.join();
+}
+// host threads of the ingest: XHE_INGEST_THREADS, else the machine's threads, at most 16
+static inline unsigned ingest_thread_count() {
+    if (const char *e = getenv("XHE_INGEST_THREADS")) { unsigned v = (unsigned)strtoul(e, nullptr, 10); if (v >= 1 && v <= 256) return v; }
+    unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1 : (hc > 16 ? 16 : hc);
+}
+
+// returns false when a record is malformed (hb.structural says which) or the ledger view is inconsistent (hb.bad_ledger)
+static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv) {
+    constexpr u32 NONE = 0xffffffffu;
+    const unsigned threads = ingest_thread_count();
+    static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!show_times) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[xhe ingest] %-28s %.3f ms\n", what, std::chrono::duration<double>(now - t_last).count() * 1e3);
+        t_last = now;
+    };
+    hb.n_txs = n;
+    // ---- the ledger view's own indices ----
+    for (u64 i = 0; i < lv.n_balances; i++) if (lv.balance_account[i] >= lv.n_accounts) { hb.bad_ledger = true; return false; }
+    for (u64 i = 0; i < lv.n_multisig; i++)
+        if (lv.multisig_account[i] >= lv.n_accounts || lv.multisig_offsets[i + 1] < lv.multisig_offsets[i]) { hb.bad_ledger = true; return false; }
+    if (lv.n_multisig && lv.multisig_offsets[0] != 0) { hb.bad_ledger = true; return false; }
+
+    // ---- pass A (parallel): parse every record ----
+    std::vector<tx_record> recs(n);
+    {
+        std::atomic<u64> first_bad(~0ull);
+        ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
+            for (u64 i = lo; i < hi; i++) {
+                bool ok = offsets[i + 1] >= offsets[i] && record_parse(recs[i], records + offsets[i], offsets[i + 1] - offsets[i]);
+                if (ok && recs[i].type == 3) {         // a HashMap cannot hold one asset twice (src/tx/mod.rs:78)
+                    const tx_record &t = recs[i];
+                    for (u32 a = 0; a < t.n_items && ok; a++)
+                        for (u32 b = a + 1; b < t.n_items; b++)
+                            if (!memcmp(t.payload() + 32 + 40 * a, t.payload() + 32 + 40 * b, 32)) { ok = false; break; }
+                }
+                if (!ok) {                             // the first bad record of a range is enough: the verdict names the smallest index
+                    u64 seen = first_bad.load();
+                    while (i < seen && !first_bad.compare_exchange_weak(seen, i)) {}
+                    break;
+                }
+            }
+        });
+        if (first_bad.load() != ~0ull) { hb.structural = {0, XHE_ERR_MALFORMED, (int64_t)first_bad.load()}; return false; }
+    }
+    lap("records parsed");
+    u32 max_lg = 6;
+    for (u64 i = 0; i < n; i++) if (recs[i].lg() > max_lg) max_lg = recs[i].lg();
     if (max_lg > 15) max_lg = 15;      // party capacity 512 (src/proofs.rs:20); larger proofs fail in the range-proof stage
     hb.nm_cap = 1u << max_lg;
     hb.n_static = 2 + 2 * hb.nm_cap;
 
     // ---- byte buffer ----
-    u64 rec_bytes = offsets[n];
+    const u64 rec_bytes = offsets[n];
     hb.keys_base = (rec_bytes + 63) & ~63ull;
     hb.cts_base = hb.keys_base + 32 * lv.n_accounts;
-    u64 n_signers = lv.n_multisig ? lv.multisig_offsets[lv.n_multisig] : 0;
+    const u64 n_signers = lv.n_multisig ? lv.multisig_offsets[lv.n_multisig] : 0;
     hb.signers_base = hb.cts_base + 64 * lv.n_balances;
     // the device's byte buffer: records | account keys | ledger ciphertexts | multisig signer keys | 64 spare bytes.  It is
-    // assembled from the caller's arrays when the batch is uploaded (byte_pieces); no host copy is kept.
+    // assembled from the caller's arrays when the batch is uploaded; no host copy is kept.
     hb.rec_bytes = rec_bytes; hb.n_signer_keys = n_signers;
     hb.bytes_len = hb.signers_base + 32 * n_signers + 64;
 
-    // ---- ledger key structure ----
+    // ---- ledger key structure (read-only from here on) ----
     std::unordered_map<key32, u32, byte_key_hash<32>> account_of;
     account_of.reserve(lv.n_accounts * 2 + 16);
     for (u64 i = 0; i < lv.n_accounts; i++) account_of.emplace(make_key32(lv.account_keys + 32 * i), (u32)i);
@@ -111,232 +191,387 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     slot_of.reserve(lv.n_balances * 2 + 16);
     auto slot_key = [](const u8 *asset, u32 account) { key36 k; memcpy(k.b, asset, 32); memcpy(k.b + 32, &account, 4); return k; };
     for (u64 i = 0; i < lv.n_balances; i++) slot_of.emplace(slot_key(lv.balance_assets + 32 * i, lv.balance_account[i]), (u32)i);
-    struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
-    std::unordered_map<u32, ms_cfg> ms_of;
-    for (u64 i = 0; i < lv.n_multisig; i++) {
-        ms_cfg c; c.threshold = lv.multisig_threshold[i];
-        for (u32 j = lv.multisig_offsets[i]; j < lv.multisig_offsets[i + 1]; j++) c.signer_off.push_back(hb.signers_base + 32ull * j);
-        ms_of[lv.multisig_account[i]] = c;
-    }
     hb.multisig_set_by.assign(lv.n_accounts, -1);
 
-    // ---- point index allocation ----
-    auto new_point = [&](u64 off, u32 rp_tx, u32 early = 0) -> u32 {          // early: 1 = ledger scan input, 2 = key
-        if (early == 1) hb.early_decs.push_back((u32)hb.decs.size());
-        if (early == 2) hb.key_decs.push_back((u32)hb.decs.size());
-        if (early == 0) hb.bulk_decs.push_back((u32)hb.decs.size());
-        hb.decs.push_back({off, early, 0u}); hb.rp_dec_tx.push_back(rp_tx);
-        return hb.n_static + (u32)hb.decs.size() - 1;
-    };
-    std::unordered_map<u32, u32> sig_key_slot;        // point idx of a signing key -> position in sig_keys
-    auto key_slot_of = [&](u32 pt) -> u32 {
-        auto it = sig_key_slot.find(pt);
-        if (it != sig_key_slot.end()) return it->second;
-        u32 slot = (u32)hb.sig_keys.size();
-        hb.sig_keys.push_back(pt); sig_key_slot.emplace(pt, slot);
-        return slot;
-    };
-    std::unordered_map<u32, u32> account_pt;          // account idx -> point idx
-    std::unordered_map<u64, u32> signer_pt;           // byte offset of a signer key -> point idx
-    std::unordered_map<u32, u32> used_slot;           // ledger balance idx -> used-slot idx
-    std::vector<u32> slot_pt;                         // used-slot idx -> point idx of initial C (D = +1)
-    std::vector<std::vector<dev_op>> slot_ops;        // per used slot, in order
-    auto get_account_pt = [&](u32 a) { auto it = account_pt.find(a); if (it != account_pt.end()) return it->second; u32 p = new_point(hb.keys_base + 32ull * a, 0xffffffffu, 2); account_pt[a] = p; return p; };
-    // returns used-slot idx; *fresh = true when this is the first touch
-    auto touch_slot = [&](u32 bal_idx, bool *fresh) {
-        auto it = used_slot.find(bal_idx);
-        if (it != used_slot.end()) { *fresh = false; return it->second; }
-        u32 u = (u32)slot_pt.size();
-        used_slot[bal_idx] = u;
-        u32 p = new_point(hb.cts_base + 64ull * bal_idx, 0xffffffffu, 1);
-        new_point(hb.cts_base + 64ull * bal_idx + 32, 0xffffffffu, 1);
-        slot_pt.push_back(p); hb.slot_of_used.push_back(bal_idx);
-        slot_ops.emplace_back();
-        dev_op init{}; init.slot = u; init.kind = 0; init.c_pt = p; init.d_pt = p + 1; init.emit = 0xffffffffu; init.first = 1;
-        slot_ops[u].push_back(init);
-        *fresh = true;
-        return u;
-    };
-
-    hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE); hb.apply_err.assign(n, ERRKEY_NONE);
+    // ---- prefix sums over the shapes: transfers, commitments, terms, challenges, segments ----
+    std::vector<u32> xf_base(n + 1), cm_base(n + 1), cm_term(n), xf_term(n), seg_base(n + 1);
     {
-        // sizes are known from the parsed records up to the ledger's first-touch points: reserve once
-        u64 n_xf = 0, n_cm = 0, n_pts = 0, n_ms = 0;
+        u32 x = 0, c = 0, term = 0, sg = 0;
         for (u64 i = 0; i < n; i++) {
-            u64 T = recs[i].transfer_off.size(), A = recs[i].n_commitments;
-            n_xf += T; n_cm += A; n_ms += recs[i].n_multisig; n_pts += 4 + 2ull * recs[i].lg() + 6 * T + 4 * A + 1;
+            const u32 T = (u32)recs[i].transfer_off.size(), A = recs[i].n_commitments;
+            xf_base[i] = x; cm_base[i] = c; seg_base[i] = sg;
+            cm_term[i] = term; term += 7 * A; xf_term[i] = term; term += 8 * T;      // sigma terms first and contiguous: the sigma-only check uses them
+            x += T; c += A; sg += 2 + A + 2 * T;
         }
-        n_pts += 2 * n_xf + 2 * n_cm;                  // ledger ciphertexts touched for the first time, receiver keys
-        hb.decs.reserve(n_pts); hb.rp_dec_tx.reserve(n_pts); hb.early_decs.reserve(5 * n_xf + 2 * n_cm); hb.key_decs.reserve(n + n_xf); hb.bulk_decs.reserve(n_pts);
-        hb.cms.reserve(n_cm); hb.xfers.reserve(n_xf); hb.sigs.reserve(n + n_ms); hb.segs.reserve(2 * n + n_cm + 2 * n_xf);
+        xf_base[n] = x; cm_base[n] = c; seg_base[n] = sg;
+        hb.sigma_terms = term;
     }
-    std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_of;
-    hb.lg_groups.assign(16, {});
-    u32 term = 0, chal = 0;
-    auto raise = [&](u64 i, u32 key) { if (key < hb.tx_err[i]) hb.tx_err[i] = key; };
-    auto raise_state = [&](u64 i, u32 key) { raise(i, key); if (key < hb.apply_err[i]) hb.apply_err[i] = key; };
+    const u32 n_xf = xf_base[n], n_cm = cm_base[n];
 
-    // pass 1: sigma-proof terms first so that they are contiguous (the sigma-only multiscalar check uses them)
-    std::vector<u32> cm_term(n), xf_term(n);
-    for (u64 i = 0; i < n; i++) { cm_term[i] = term; term += 7 * recs[i].n_commitments; xf_term[i] = term; term += 8 * (u32)recs[i].transfer_off.size(); }
-    hb.sigma_terms = term;
-
-    for (u64 i = 0; i < n; i++) {
-        const tx_record &t = recs[i];
-        dev_tx &d = hb.txs[i];
-        memset(&d, 0, sizeof d);
-        u64 rec = offsets[i];
-        d.rec = rec; d.pre_off = t.pre_off; d.pre_len = t.pre_len; d.payload_off = t.payload_off; d.rp_off = t.rp_off; d.cm_off = t.cm_off;
-        d.ms_off = t.ms_off; d.sig_off = t.sig_off;
-        d.n_transfers = (u16)t.transfer_off.size(); d.n_commitments = t.n_commitments; d.n_multisig = t.n_multisig; d.n_items = t.n_items;
-        d.type = t.type; d.lg = (u8)t.lg(); d.version = t.version; d.flags = t.flags; d.m = t.m(); d.fee = t.fee; d.nonce = t.nonce;
-        d.hash_idx = 0xffffffffu;
-        d.xfer_first = (u32)hb.xfers.size(); d.cm_first = (u32)hb.cms.size();
-        u32 A = t.n_commitments, T = d.n_transfers, lg = t.lg();
-        d.chal_off = chal; chal += 2 * A + 2 * T + 4 + lg;
-        d.rp_term_off = term; term += 4 + 2 * lg + A + T;
-        if (lg <= 15) { d.rp_row = (u32)hb.lg_groups[lg].size(); hb.lg_groups[lg].push_back((u32)i); }
-        {
-            transcript_shape sh{t.type, A, T, t.n_items, d.m, lg};
-            if (transcript_shape_supported(sh)) {
-                auto it = tmpl_of.find(sh);
-                d.tmpl_off = it != tmpl_of.end() ? it->second : (tmpl_of[sh] = build_transcript_template(hb.tmpl, sh));
-                d.seg_off = (u32)hb.segs.size();
-                transcript_segments(hb.segs, t);
-            } else { d.tmpl_off = TT_NONE; hb.serial_txs.push_back((u32)i); }
-        }
-
-        // per-tx points: range proof, commitments, transfers
-        d.rp_pt = new_point(rec + t.rp_off, (u32)i);
-        for (u32 k = 1; k < 4; k++) new_point(rec + t.rp_off + 32 * k, (u32)i);
-        for (u32 k = 0; k < 2 * lg; k++) new_point(rec + t.rp_off + 224 + 32 * k, (u32)i);
-
-        // source account, nonce (verify.rs:210-221)
-        auto acc_it = account_of.find(make_key32(t.source()));
-        bool src_known = acc_it != account_of.end();
-        u32 src_acc = src_known ? acc_it->second : 0;
-        if (!src_known) raise_state(i, errkey(ST_NONCE, 0, 0, XHE_ERR_STATE));
-        else if (lv.account_nonces[src_acc] != t.nonce) raise(i, errkey(ST_NONCE, 0, 1, XHE_ERR_INVALID_NONCE));
-        d.src_pt = src_known ? get_account_pt(src_acc) : new_point(rec + t.pre_off + 1, 0xffffffffu, 2);
-        if (!record_commitment_assets_ok(t)) raise(i, errkey(ST_ASSETS, 0, 0, XHE_ERR_FORMAT));
-
-        // main signature over pre-image || multisig entries (verify.rs:253-256)
-        {
-            dev_sig s{}; s.tx = (u32)i; s.key_pt = d.src_pt; s.key_off = rec + t.pre_off + 1; s.msg_off = rec + t.pre_off; s.msg_len = t.pre_len + 65u * t.n_multisig;
-            s.hash_idx = 0xffffffffu; s.sig_off = rec + t.sig_off; s.err_key = errkey(ST_SIGNATURE, 0, 0, XHE_ERR_SIGNATURE); s.key_err_key = 0;
-            s.key_slot = key_slot_of(s.key_pt);
-            hb.sigs.push_back(s);
-        }
-        // multisig (verify.rs:259-292)
-        auto ms_it = src_known ? ms_of.find(src_acc) : ms_of.end();
-        if (ms_it != ms_of.end()) {
-            const ms_cfg &cfg = ms_it->second;
-            if (!t.has_multisig() || t.n_multisig == 0 || t.n_multisig != cfg.threshold) raise(i, errkey(ST_MULTISIG, 0, 0, XHE_ERR_FORMAT));
-            else {
-                d.hash_idx = (u32)hb.ms_hash_tx.size(); hb.ms_hash_tx.push_back((u32)i);
-                for (u32 k = 0; k < t.n_multisig; k++) {
-                    u8 idx = t.ms_entry(k)[0];
-                    for (u32 j = 0; j < t.n_multisig; j++) if (j != k && t.ms_entry(j)[0] == idx) raise(i, errkey(ST_MULTISIG, k, 1, XHE_ERR_FORMAT));
-                    if (idx < cfg.signer_off.size()) {
-                        u64 koff = cfg.signer_off[idx];
-                        auto sp = signer_pt.find(koff);
-                        u32 kp = sp != signer_pt.end() ? sp->second : (signer_pt[koff] = new_point(koff, 0xffffffffu, 2));
-                        dev_sig s{}; s.tx = (u32)i; s.key_pt = kp; s.key_off = koff; s.msg_off = 0; s.msg_len = 32; s.hash_idx = d.hash_idx;
-                        s.sig_off = rec + t.ms_off + 65ull * k + 1; s.err_key = errkey(ST_MULTISIG, k, 3, XHE_ERR_SIGNATURE);
-                        s.key_err_key = errkey(ST_MULTISIG, k, 2, XHE_ERR_DECOMPRESSION);
-                        s.key_slot = key_slot_of(kp);
-                        hb.sigs.push_back(s);
-                    }
-                }
-            }
-        } else if (t.has_multisig()) raise(i, errkey(ST_MULTISIG, 0, 0, XHE_ERR_FORMAT));
-
-        // transfers' points: C, D_s, D_r, Y_0, Y_1, Y_2
-        std::vector<u32> xf_pt(T);
-        for (u32 k = 0; k < T; k++) {
-            u64 o = rec + t.transfer_off[k];
-            u64 po = rec + t.transfer_off[k] + t.transfer_len[k] - 160;
-            xf_pt[k] = new_point(o + 64, 0xffffffffu, 1); new_point(o + 96, 0xffffffffu, 1); new_point(o + 128, 0xffffffffu, 1);
-            new_point(po, 0xffffffffu); new_point(po + 32, 0xffffffffu); new_point(po + 64, 0xffffffffu);
-        }
-        // commitments (verify.rs:296-341)
-        for (u32 k = 0; k < A; k++) {
-            dev_cm c{}; c.tx = (u32)i; c.idx = k; c.off = rec + t.cm_off + 256ull * k;
-            c.pt = new_point(c.off + 32, 0xffffffffu); new_point(c.off + 64, 0xffffffffu); new_point(c.off + 96, 0xffffffffu); new_point(c.off + 128, 0xffffffffu);
-            c.term_off = cm_term[i] + 7 * k;
-            c.src_ct_pt = 0; c.slot_pt = 0; c.first_touch = 0;
-            const u8 *asset = t.commitment(k);
-            auto sl = src_known ? slot_of.find(slot_key(asset, src_acc)) : slot_of.end();
-            u32 cm_index = (u32)hb.cms.size();
-            if (sl == slot_of.end()) raise_state(i, errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
-            else {
-                bool fresh; u32 u = touch_slot(sl->second, &fresh);
-                c.slot_pt = slot_pt[u]; c.first_touch = fresh ? 1 : 0;
-                // get_sender_output_ct (verify.rs:107-144): transfers of this asset, burn / contract amount, fee
-                for (u32 x = 0; x < T; x++)
-                    if (!memcmp(asset, t.transfer(x), 32)) {
-                        dev_op op{}; op.slot = u; op.kind = 1; op.emit = 0xffffffffu; op.first = 0;
-                        op.c_pt = xf_pt[x]; op.d_pt = xf_pt[x] + 1;      // (C, D_sender)
-                        slot_ops[u].push_back(op);
-                    }
+    // ---- pass B (parallel): ledger look-ups of every transaction ----
+    std::vector<u32> src_acc(n), xf_acc(n_xf), xf_bal(n_xf), cm_bal(n_cm);
+    std::vector<u16> xf_cm(n_xf);                      // the source commitment with the transfer's asset (0xffff: none), so that the ordered walk reads no record bytes
+    std::vector<u64> cm_amount(n_cm);                  // plain amount leaving the slot besides the fee: burn, contract deposit
+    ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
+        for (u64 i = lo; i < hi; i++) {
+            const tx_record &t = recs[i];
+            auto a = account_of.find(make_key32(t.source()));
+            const u32 sa = a == account_of.end() ? NONE : a->second;
+            src_acc[i] = sa;
+            for (u32 k = 0; k < t.n_commitments; k++) {
+                const u8 *asset = t.commitment(k);
+                u32 b = NONE;
+                if (sa != NONE) { auto sl = slot_of.find(slot_key(asset, sa)); if (sl != slot_of.end()) b = sl->second; }
+                cm_bal[cm_base[i] + k] = b;
                 u64 amount = 0;
                 if (t.type == 1) { if (!memcmp(asset, t.payload(), 32)) amount = rec_be64(t.payload() + 32); }
                 else if (t.type == 3) { for (u32 x = 0; x < t.n_items; x++) if (!memcmp(asset, t.payload() + 32 + 40 * x, 32)) amount = rec_be64(t.payload() + 64 + 40 * x); }
-                if (amount) { dev_op op{}; op.slot = u; op.kind = 2; op.amount = amount; op.emit = 0xffffffffu; slot_ops[u].push_back(op); }
-                dev_op fin{}; fin.slot = u; fin.kind = 2; fin.amount = rec_is_zero32(asset) ? t.fee : 0; fin.emit = cm_index;
-                slot_ops[u].push_back(fin);
+                cm_amount[cm_base[i] + k] = amount;
             }
-            hb.cms.push_back(c);
-        }
-        // transfers (verify.rs:345-395)
-        for (u32 k = 0; k < T; k++) {
-            dev_xfer x{}; x.tx = (u32)i; x.idx = k; x.off = rec + t.transfer_off[k]; x.proof_off = rec + t.transfer_off[k] + t.transfer_len[k] - 160;
-            x.pt = xf_pt[k];
-            x.term_off = xf_term[i] + 8 * k;
-            const u8 *asset = t.transfer(k), *dest = t.transfer(k) + 32;
-            auto da = account_of.find(make_key32(dest));
-            if (da == account_of.end()) {
-                x.dest_pt = new_point(x.off + 32, 0xffffffffu);
-                x.state_err = 1;
-                raise_state(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE));
-            } else {
-                x.dest_pt = get_account_pt(da->second);
-                auto sl = slot_of.find(slot_key(asset, da->second));
-                if (sl == slot_of.end()) { x.state_err = 1; raise_state(i, errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE)); }
-                else {
-                    bool fresh; u32 u = touch_slot(sl->second, &fresh);
-                    x.slot_pt = slot_pt[u]; x.first_touch = fresh ? 1 : 0;
-                    dev_op op{}; op.slot = u; op.kind = 0; op.c_pt = x.pt; op.d_pt = x.pt + 2; op.emit = 0xffffffffu;
-                    slot_ops[u].push_back(op);
-                }
-            }
-            hb.xfers.push_back(x);
-        }
-        // MultiSig payload rules and state update (verify.rs:401-428)
-        if (t.type == 2) {
-            if (!record_multisig_payload_ok(t)) raise(i, errkey(ST_TRANSFER, 0, 0, XHE_ERR_FORMAT));
-            else if (src_known) {
-                if (t.n_items == 0) ms_of.erase(src_acc);
-                else {
-                    ms_cfg c; c.threshold = t.payload()[0];
-                    for (u32 k = 0; k < t.n_items; k++) c.signer_off.push_back(rec + t.payload_off + 1 + 32ull * k);
-                    ms_of[src_acc] = c;
-                }
-                hb.multisig_set_by[src_acc] = (int64_t)i;
+            const u8 *last_dest = nullptr; u32 last_acc = NONE;
+            for (u32 k = 0; k < (u32)t.transfer_off.size(); k++) {
+                const u8 *asset = t.transfer(k), *dest = asset + 32;
+                u32 da;
+                if (last_dest && !memcmp(last_dest, dest, 32)) da = last_acc;
+                else { auto d = account_of.find(make_key32(dest)); da = d == account_of.end() ? NONE : d->second; last_dest = dest; last_acc = da; }
+                u32 b = NONE;
+                if (da != NONE) { auto sl = slot_of.find(slot_key(asset, da)); if (sl != slot_of.end()) b = sl->second; }
+                xf_acc[xf_base[i] + k] = da; xf_bal[xf_base[i] + k] = b;
+                u16 same = 0xffff;
+                for (u32 c = 0; c < t.n_commitments && c < 0xffff; c++) if (!memcmp(asset, t.commitment(c), 32)) { same = (u16)c; break; }
+                xf_cm[xf_base[i] + k] = same;
             }
         }
-        if (lg > 15 || ((u64)64 * d.m != (1ull << lg))) { /* range-proof stage reports it */ }
+    });
+
+    lap("ledger look-ups");
+    // ---- decode positions: one block per transaction, then the points shared between transactions ----
+    // block: range proof (4 + 2 lg) | source key if the ledger does not know it | per transfer C, D_s, D_r, Y_0, Y_1, Y_2 |
+    // per commitment C_new, Y_0, Y_1, Y_2 | destination keys the ledger does not know
+    std::vector<u32> blk(n + 1), early_base(n + 1), key_base(n + 1), bulk_base(n + 1);
+    {
+        u32 p = 0, e = 0, k = 0, b = 0;
+        for (u64 i = 0; i < n; i++) {
+            const u32 T = (u32)recs[i].transfer_off.size(), A = recs[i].n_commitments, lg = recs[i].lg();
+            u32 unknown_dests = 0;
+            for (u32 x = 0; x < T; x++) if (xf_acc[xf_base[i] + x] == NONE) unknown_dests++;
+            const u32 own_key = src_acc[i] == NONE ? 1u : 0u;
+            blk[i] = p; early_base[i] = e; key_base[i] = k; bulk_base[i] = b;
+            p += 4 + 2 * lg + own_key + 6 * T + 4 * A + unknown_dests;
+            e += 3 * T; k += own_key; b += 4 + 2 * lg + 3 * T + 4 * A + unknown_dests;
+        }
+        blk[n] = p; early_base[n] = e; key_base[n] = k; bulk_base[n] = b;
     }
+
+    lap("prefix sums");
+    // ---- pass C (sequential): everything the order of the transactions decides ----
+    std::vector<dev_dec> shared_decs;                  // positions blk[n] + index
+    std::vector<u32> shared_early, shared_key;
+    auto new_shared = [&](u64 off, u32 early) -> u32 {
+        const u32 pos = blk[n] + (u32)shared_decs.size();
+        shared_decs.push_back({off});
+        (early == 1 ? shared_early : shared_key).push_back(pos);
+        return pos;
+    };
+    std::vector<u32> acc_pos(lv.n_accounts, NONE), acc_keyslot(lv.n_accounts, NONE), used_slot(lv.n_balances, NONE);
+    std::vector<u32> slot_pos, ops_count;               // per used slot: position of its initial C (D = +1), operations so far
+    std::unordered_map<u64, u32> signer_pos;           // byte offset of a signer key -> position
+    std::unordered_map<u32, u32> pos_keyslot;          // position of a signer / unknown-source key -> position in sig_keys
+    struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
+    std::vector<ms_cfg> cfgs;
+    std::vector<int32_t> cfg_of(lv.n_accounts, -1);
+    for (u64 i = 0; i < lv.n_multisig; i++) {
+        ms_cfg c; c.threshold = lv.multisig_threshold[i];
+        for (u32 j = lv.multisig_offsets[i]; j < lv.multisig_offsets[i + 1]; j++) c.signer_off.push_back(hb.signers_base + 32ull * j);
+        cfg_of[lv.multisig_account[i]] = (int32_t)cfgs.size(); cfgs.push_back(c);
+    }
+    auto account_position = [&](u32 a) { if (acc_pos[a] == NONE) acc_pos[a] = new_shared(hb.keys_base + 32ull * a, 2); return acc_pos[a]; };
+    auto touch_slot = [&](u32 bal, bool *fresh) {
+        if (used_slot[bal] != NONE) { *fresh = false; return used_slot[bal]; }
+        const u32 u = (u32)slot_pos.size();
+        used_slot[bal] = u;
+        const u32 p = new_shared(hb.cts_base + 64ull * bal, 1);
+        new_shared(hb.cts_base + 64ull * bal + 32, 1);
+        slot_pos.push_back(p); hb.slot_of_used.push_back(bal); ops_count.push_back(1);       // operation 0: the initial balance
+        *fresh = true;
+        return u;
+    };
+    auto keyslot_of_pos = [&](u32 pos) {
+        auto it = pos_keyslot.find(pos);
+        if (it != pos_keyslot.end()) return it->second;
+        const u32 s = (u32)hb.sig_keys.size();
+        hb.sig_keys.push_back(hb.n_static + pos); pos_keyslot.emplace(pos, s);
+        return s;
+    };
+    // what pass C leaves for pass D
+    std::vector<u32> src_pos(n), src_keyslot(n), sig_base(n + 1), step_err(n, ERRKEY_NONE), tmpl_of_tx(n), rp_row(n, 0), hash_idx(n, NONE);
+    std::vector<u32> cm_slot(n_cm, NONE), cm_local(n_cm, 0), xf_slot(n_xf, NONE), xf_local(n_xf, 0), xf_dest_pos(n_xf, NONE);
+    std::vector<u8> cm_fresh(n_cm, 0), xf_fresh(n_xf, 0);
+    struct ms_entry { u32 tx, k, key_pos, key_slot; u64 key_off; };
+    std::vector<ms_entry> ms_entries;                  // co-signatures to verify, in transaction order
+    std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_map;
+    transcript_shape last_shape{255, 0, 0, 0, 0, 0}; u32 last_tmpl = TT_NONE;
+    hb.lg_groups.assign(16, {});
+    {
+        u32 sigs = 0;
+        for (u64 i = 0; i < n; i++) {
+            const tx_record &t = recs[i];
+            const u32 T = (u32)t.transfer_off.size(), A = t.n_commitments, lg = t.lg();
+            const u64 rec = offsets[i];
+            auto raise = [&](u32 key) { if (key < step_err[i]) step_err[i] = key; };
+            if (lg <= 15) { rp_row[i] = (u32)hb.lg_groups[lg].size(); hb.lg_groups[lg].push_back((u32)i); }
+            {
+                transcript_shape sh{t.type, A, T, t.n_items, t.m(), lg};
+                if (!(sh == last_shape)) {
+                    last_shape = sh;
+                    if (!transcript_shape_supported(sh)) last_tmpl = TT_NONE;
+                    else { auto it = tmpl_map.find(sh); last_tmpl = it != tmpl_map.end() ? it->second : (tmpl_map[sh] = build_transcript_template(hb.tmpl, sh)); }
+                }
+                tmpl_of_tx[i] = last_tmpl;
+                if (last_tmpl == TT_NONE) hb.serial_txs.push_back((u32)i);
+            }
+            // source key and its place among the distinct signing keys
+            const u32 sa = src_acc[i];
+            sig_base[i] = sigs; sigs++;
+            if (sa != NONE) {
+                src_pos[i] = account_position(sa);
+                if (acc_keyslot[sa] == NONE) { acc_keyslot[sa] = (u32)hb.sig_keys.size(); hb.sig_keys.push_back(hb.n_static + src_pos[i]); }
+                src_keyslot[i] = acc_keyslot[sa];
+            } else {
+                src_pos[i] = blk[i] + 4 + 2 * lg;      // the key inside the record: a point of its own
+                src_keyslot[i] = (u32)hb.sig_keys.size(); hb.sig_keys.push_back(hb.n_static + src_pos[i]);
+            }
+            // multisig (verify.rs:259-292)
+            const int32_t ci = sa != NONE ? cfg_of[sa] : -1;
+            if (ci >= 0) {
+                const ms_cfg &cfg = cfgs[(size_t)ci];
+                if (!t.has_multisig() || t.n_multisig == 0 || t.n_multisig != cfg.threshold) raise(errkey(ST_MULTISIG, 0, 0, XHE_ERR_FORMAT));
+                else {
+                    hash_idx[i] = (u32)hb.ms_hash_tx.size(); hb.ms_hash_tx.push_back((u32)i);
+                    for (u32 k = 0; k < t.n_multisig; k++) {
+                        const u8 idx = t.ms_entry(k)[0];
+                        for (u32 j = 0; j < t.n_multisig; j++) if (j != k && t.ms_entry(j)[0] == idx) raise(errkey(ST_MULTISIG, k, 1, XHE_ERR_FORMAT));
+                        if (idx < cfg.signer_off.size()) {
+                            const u64 koff = cfg.signer_off[idx];
+                            auto sp = signer_pos.find(koff);
+                            const u32 kp = sp != signer_pos.end() ? sp->second : (signer_pos[koff] = new_shared(koff, 2));
+                            ms_entries.push_back({(u32)i, k, kp, keyslot_of_pos(kp), koff});
+                            sigs++;
+                        }
+                    }
+                }
+            } else if (t.has_multisig()) raise(errkey(ST_MULTISIG, 0, 0, XHE_ERR_FORMAT));
+            // commitments (verify.rs:296-341): the slot, and its operations: minus every transfer of the asset, minus the plain
+            // amount (burn, contract deposit), minus the fee with the emission of the sender's new ciphertext
+            for (u32 k = 0; k < A; k++) {
+                const u32 c = cm_base[i] + k, bal = cm_bal[c];
+                if (bal == NONE) continue;
+                bool fresh; const u32 u = touch_slot(bal, &fresh);
+                cm_slot[c] = u; cm_fresh[c] = fresh ? 1 : 0; cm_local[c] = ops_count[u];
+                u32 cnt = 1;
+                for (u32 x = 0; x < T; x++) if (xf_cm[xf_base[i] + x] == k) cnt++;
+                if (cm_amount[c]) cnt++;
+                ops_count[u] += cnt;
+            }
+            // transfers (verify.rs:345-395)
+            for (u32 k = 0; k < T; k++) {
+                const u32 x = xf_base[i] + k, da = xf_acc[x];
+                if (da == NONE) continue;
+                xf_dest_pos[x] = account_position(da);
+                if (xf_bal[x] == NONE) continue;
+                bool fresh; const u32 u = touch_slot(xf_bal[x], &fresh);
+                xf_slot[x] = u; xf_fresh[x] = fresh ? 1 : 0; xf_local[x] = ops_count[u]++;
+            }
+            // MultiSig payload rules and state update (verify.rs:401-428)
+            if (t.type == 2) {
+                if (!record_multisig_payload_ok(t)) raise(errkey(ST_TRANSFER, 0, 0, XHE_ERR_FORMAT));
+                else if (sa != NONE) {
+                    if (t.n_items == 0) cfg_of[sa] = -1;
+                    else {
+                        ms_cfg c; c.threshold = t.payload()[0];
+                        for (u32 k = 0; k < t.n_items; k++) c.signer_off.push_back(rec + t.payload_off + 1 + 32ull * k);
+                        cfg_of[sa] = (int32_t)cfgs.size(); cfgs.push_back(c);
+                    }
+                    hb.multisig_set_by[sa] = (int64_t)i;
+                }
+            }
+        }
+        sig_base[n] = sigs;
+    }
+    lap("ordered walk");
+    const u32 n_slots = (u32)slot_pos.size();
+    std::vector<u32> slot_base(n_slots + 1);
+    { u32 o = 0; for (u32 u = 0; u < n_slots; u++) { slot_base[u] = o; o += ops_count[u]; } slot_base[n_slots] = o; }
+
+    // ---- sizes ----
+    const u32 n_decs = blk[n] + (u32)shared_decs.size();
+    hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE); hb.apply_err.assign(n, ERRKEY_NONE);
+    hb.cms.resize(n_cm); hb.xfers.resize(n_xf); hb.sigs.resize(sig_base[n]); hb.segs.resize(seg_base[n]);
+    hb.decs.resize(n_decs);
+    std::copy(shared_decs.begin(), shared_decs.end(), hb.decs.begin() + blk[n]);
+    hb.early_decs.resize(early_base[n] + shared_early.size()); std::copy(shared_early.begin(), shared_early.end(), hb.early_decs.begin() + early_base[n]);
+    hb.key_decs.resize(key_base[n] + shared_key.size()); std::copy(shared_key.begin(), shared_key.end(), hb.key_decs.begin() + key_base[n]);
+    hb.bulk_decs.resize(bulk_base[n]);
+    hb.ops.resize(slot_base[n_slots]);
+    hb.slot_last_op.resize(n_slots);
+    for (u32 u = 0; u < n_slots; u++) {
+        dev_op init{}; init.slot = u; init.kind = 0; init.c_pt = hb.n_static + slot_pos[u]; init.d_pt = init.c_pt + 1; init.emit = NONE; init.first = 1;
+        hb.ops[slot_base[u]] = init;
+        hb.slot_last_op[u] = slot_base[u + 1] - 1;
+    }
+    hb.emit_base = hb.n_static + n_decs;
+    hb.n_emit = 2 * n_cm;
+    hb.n_points = hb.emit_base + hb.n_emit;
+    // challenges and range-proof terms follow in transaction order
+    std::vector<u32> chal_off(n), rp_term(n);
+    {
+        u32 chal = 0, term = hb.sigma_terms;
+        for (u64 i = 0; i < n; i++) {
+            const u32 T = (u32)recs[i].transfer_off.size(), A = recs[i].n_commitments, lg = recs[i].lg();
+            chal_off[i] = chal; chal += 2 * A + 2 * T + 4 + lg;
+            rp_term[i] = term; term += 4 + 2 * lg + A + T;
+        }
+        hb.n_chal = chal; hb.static_term_off = term; hb.n_terms = term + hb.n_static;
+    }
+    // co-signatures by transaction: ms_entries is in transaction order, so a transaction's entries follow its main signature
+    std::vector<u32> ms_first(n + 1, 0);
+    { for (auto &e : ms_entries) ms_first[e.tx + 1]++; for (u64 i = 0; i < n; i++) ms_first[i + 1] += ms_first[i]; }
+
+    lap("tables sized");
+    // ---- pass D (parallel): the descriptors ----
+    ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
+        for (u64 i = lo; i < hi; i++) {
+            const tx_record &t = recs[i];
+            dev_tx &d = hb.txs[i];
+            memset(&d, 0, sizeof d);
+            const u64 rec = offsets[i];
+            const u32 T = (u32)t.transfer_off.size(), A = t.n_commitments, lg = t.lg();
+            d.rec = rec; d.pre_off = t.pre_off; d.pre_len = t.pre_len; d.payload_off = t.payload_off; d.rp_off = t.rp_off; d.cm_off = t.cm_off;
+            d.ms_off = t.ms_off; d.sig_off = t.sig_off;
+            d.n_transfers = (u16)T; d.n_commitments = t.n_commitments; d.n_multisig = t.n_multisig; d.n_items = t.n_items;
+            d.type = t.type; d.lg = (u8)lg; d.version = t.version; d.flags = t.flags; d.m = t.m(); d.fee = t.fee; d.nonce = t.nonce;
+            d.hash_idx = hash_idx[i];
+            d.xfer_first = xf_base[i]; d.cm_first = cm_base[i];
+            d.chal_off = chal_off[i]; d.rp_term_off = rp_term[i]; d.rp_row = rp_row[i];
+            d.tmpl_off = tmpl_of_tx[i]; d.seg_off = seg_base[i];
+            {
+                u32 *sg = hb.segs.data() + seg_base[i];
+                *sg++ = t.pre_off; *sg++ = t.rp_off;
+                for (u32 k = 0; k < A; k++) *sg++ = t.cm_off + 256 * k;
+                for (u32 k = 0; k < T; k++) { *sg++ = t.transfer_off[k]; *sg++ = t.transfer_off[k] + t.transfer_len[k] - 160; }
+            }
+            u32 key = step_err[i], akey = ERRKEY_NONE;
+            auto raise = [&](u32 k2) { if (k2 < key) key = k2; };
+            auto raise_state = [&](u32 k2) { raise(k2); if (k2 < akey) akey = k2; };
+            // the block of points
+            u32 pos = blk[i], ei = early_base[i], bi = bulk_base[i];
+            auto put = [&](u64 off, u32 early) {
+                hb.decs[pos] = {off};
+                if (early == 1) hb.early_decs[ei++] = pos; else if (early == 2) hb.key_decs[key_base[i]] = pos; else hb.bulk_decs[bi++] = pos;
+                return hb.n_static + pos++;
+            };
+            d.rp_pt = put(rec + t.rp_off, 0);
+            for (u32 k = 1; k < 4; k++) put(rec + t.rp_off + 32 * k, 0);
+            for (u32 k = 0; k < 2 * lg; k++) put(rec + t.rp_off + 224 + 32 * k, 0);
+            // source account, nonce (verify.rs:210-221)
+            const u32 sa = src_acc[i];
+            if (sa == NONE) { raise_state(errkey(ST_NONCE, 0, 0, XHE_ERR_STATE)); d.src_pt = put(rec + t.pre_off + 1, 2); }
+            else {
+                if (lv.account_nonces[sa] != t.nonce) raise(errkey(ST_NONCE, 0, 1, XHE_ERR_INVALID_NONCE));
+                d.src_pt = hb.n_static + src_pos[i];
+            }
+            if (!record_commitment_assets_ok(t)) raise(errkey(ST_ASSETS, 0, 0, XHE_ERR_FORMAT));
+            // main signature over pre-image || multisig entries (verify.rs:253-256), then the co-signatures
+            {
+                u32 si = sig_base[i];
+                dev_sig s{}; s.tx = (u32)i; s.key_pt = d.src_pt; s.key_off = rec + t.pre_off + 1; s.msg_off = rec + t.pre_off; s.msg_len = t.pre_len + 65u * t.n_multisig;
+                s.hash_idx = NONE; s.sig_off = rec + t.sig_off; s.err_key = errkey(ST_SIGNATURE, 0, 0, XHE_ERR_SIGNATURE); s.key_err_key = 0;
+                s.key_slot = src_keyslot[i];
+                hb.sigs[si++] = s;
+                for (u32 e = ms_first[i]; e < ms_first[i + 1]; e++) {
+                    const ms_entry &me = ms_entries[e];
+                    dev_sig c{}; c.tx = (u32)i; c.key_pt = hb.n_static + me.key_pos; c.key_off = me.key_off; c.msg_off = 0; c.msg_len = 32; c.hash_idx = hash_idx[i];
+                    c.sig_off = rec + t.ms_off + 65ull * me.k + 1; c.err_key = errkey(ST_MULTISIG, me.k, 3, XHE_ERR_SIGNATURE);
+                    c.key_err_key = errkey(ST_MULTISIG, me.k, 2, XHE_ERR_DECOMPRESSION);
+                    c.key_slot = me.key_slot;
+                    hb.sigs[si++] = c;
+                }
+            }
+            // transfers' points: C, D_s, D_r, Y_0, Y_1, Y_2
+            const u32 xf_pt0 = hb.n_static + pos;
+            for (u32 k = 0; k < T; k++) {
+                const u64 o = rec + t.transfer_off[k], po = o + t.transfer_len[k] - 160;
+                put(o + 64, 1); put(o + 96, 1); put(o + 128, 1);
+                put(po, 0); put(po + 32, 0); put(po + 64, 0);
+            }
+            // commitments (verify.rs:296-341)
+            for (u32 k = 0; k < A; k++) {
+                const u32 ci = cm_base[i] + k;
+                dev_cm c{}; c.tx = (u32)i; c.idx = k; c.off = rec + t.cm_off + 256ull * k;
+                c.pt = put(c.off + 32, 0); put(c.off + 64, 0); put(c.off + 96, 0); put(c.off + 128, 0);
+                c.term_off = cm_term[i] + 7 * k;
+                c.src_ct_pt = hb.emit_base + 2 * ci; c.slot_pt = 0; c.first_touch = 0;
+                const u32 u = cm_slot[ci];
+                if (u == NONE) raise_state(errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
+                else {
+                    c.slot_pt = hb.n_static + slot_pos[u]; c.first_touch = cm_fresh[ci];
+                    const u8 *asset = t.commitment(k);
+                    u32 o = slot_base[u] + cm_local[ci];
+                    // get_sender_output_ct (verify.rs:107-144): transfers of this asset, burn / contract amount, fee
+                    for (u32 x = 0; x < T; x++)
+                        if (xf_cm[xf_base[i] + x] == k) {
+                            dev_op op{}; op.slot = u; op.kind = 1; op.emit = NONE; op.first = 0;
+                            op.c_pt = xf_pt0 + 6 * x; op.d_pt = op.c_pt + 1;      // (C, D_sender)
+                            hb.ops[o++] = op;
+                        }
+                    const u64 amount = cm_amount[ci];
+                    if (amount) { dev_op op{}; op.slot = u; op.kind = 2; op.amount = amount; op.emit = NONE; hb.ops[o++] = op; }
+                    dev_op fin{}; fin.slot = u; fin.kind = 2; fin.amount = rec_is_zero32(asset) ? t.fee : 0; fin.emit = ci;
+                    hb.ops[o++] = fin;
+                }
+                hb.cms[ci] = c;
+            }
+            // transfers (verify.rs:345-395)
+            for (u32 k = 0; k < T; k++) {
+                const u32 xi = xf_base[i] + k;
+                dev_xfer x{}; x.tx = (u32)i; x.idx = k; x.off = rec + t.transfer_off[k]; x.proof_off = x.off + t.transfer_len[k] - 160;
+                x.pt = xf_pt0 + 6 * k;
+                x.term_off = xf_term[i] + 8 * k;
+                if (xf_acc[xi] == NONE) {
+                    x.dest_pt = put(x.off + 32, 0);
+                    x.state_err = 1;
+                    raise_state(errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE));
+                } else {
+                    x.dest_pt = hb.n_static + xf_dest_pos[xi];
+                    const u32 u = xf_slot[xi];
+                    if (u == NONE) { x.state_err = 1; raise_state(errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE)); }
+                    else {
+                        x.slot_pt = hb.n_static + slot_pos[u]; x.first_touch = xf_fresh[xi];
+                        dev_op op{}; op.slot = u; op.kind = 0; op.c_pt = x.pt; op.d_pt = x.pt + 2; op.emit = NONE;
+                        hb.ops[slot_base[u] + xf_local[xi]] = op;
+                    }
+                }
+                hb.xfers[xi] = x;
+            }
+            hb.tx_err[i] = key; hb.apply_err[i] = akey;
+        }
+    });
+
+    lap("descriptors written");
     // ---- transcript tiles: transactions grouped by template (first appearance order), 64 per tile ----
     {
         std::vector<u32> order;                       // template offsets in order of first appearance
         std::unordered_map<u32, std::vector<u32>> by_tmpl;
+        u32 last_to = TT_NONE; std::vector<u32> *last_vec = nullptr;
         for (u64 i = 0; i < n; i++) {
-            u32 to = hb.txs[i].tmpl_off;
+            const u32 to = tmpl_of_tx[i];
             if (to == TT_NONE) continue;
-            auto it = by_tmpl.find(to);
-            if (it == by_tmpl.end()) { order.push_back(to); it = by_tmpl.emplace(to, std::vector<u32>()).first; }
-            it->second.push_back((u32)i);
+            if (to != last_to || !last_vec) {
+                auto it = by_tmpl.find(to);
+                if (it == by_tmpl.end()) { order.push_back(to); it = by_tmpl.emplace(to, std::vector<u32>()).first; }
+                last_to = to; last_vec = &it->second;
+            }
+            last_vec->push_back((u32)i);
         }
         transcript_pass cur{0, 0, 0};
         u64 cur_words = 0;
@@ -359,21 +594,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         }
         if (cur.n_tiles) hb.tr_plan.passes.push_back(cur);
     }
-    hb.n_chal = chal;
-    hb.static_term_off = term;
-    hb.n_terms = term + hb.n_static;
-
-    // ---- ops sorted by slot, emitted ciphertext points ----
-    hb.emit_base = hb.n_static + (u32)hb.decs.size();
-    hb.n_emit = 2 * (u32)hb.cms.size();
-    hb.n_points = hb.emit_base + hb.n_emit;
-    for (size_t c = 0; c < hb.cms.size(); c++) hb.cms[c].src_ct_pt = hb.emit_base + 2 * (u32)c;
-    hb.slot_first_op.resize(slot_ops.size()); hb.slot_last_op.resize(slot_ops.size());
-    for (size_t u = 0; u < slot_ops.size(); u++) {
-        hb.slot_first_op[u] = (u32)hb.ops.size();
-        for (auto &op : slot_ops[u]) hb.ops.push_back(op);
-        hb.slot_last_op[u] = (u32)hb.ops.size() - 1;
-    }
+    lap("transcript tiles");
     return true;
 }
 

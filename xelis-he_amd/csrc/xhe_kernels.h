@@ -41,7 +41,7 @@ static constexpr u32 GEN_TABLE_CAP_MAX = 1024;    // generators per side up to w
 // One launch for the fills and copies that start a verification: job j writes n_words 32-bit words to dst,
 // copied from src or, when src is null, set to value; the last job slot carries the batch-factor seed.
 struct setup_jobs {
-    static constexpr int MAX = 12;
+    static constexpr int MAX = 16;
     u32 *dst[MAX]; const u32 *src[MAX]; u64 n_words[MAX]; u32 value[MAX];
     int n = 0;
     u32 seed[8]; u32 *seed_dst = nullptr;

@@ -4,8 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -40,18 +43,20 @@ struct xhe_batch {
     dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
-    dev_buf arena_up, arena_ws;   // the two blocks every buffer above is a range of: uploaded tables, workspace
+    dev_buf arena_up, arena_ws, arena_bytes;   // the blocks every buffer above is a range of: uploaded tables, workspace, the byte buffer
     std::vector<u32> group_off;   // per lg: offset into group_txs
+    hipEvent_t ev_uploaded = nullptr;   // fires on the copy stream when every table of the batch has arrived
     bool verified_ok = false;
     void release() {
         for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
-                           &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws})
+                           &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
             b->release();
+        if (ev_uploaded) { (void)hipEventDestroy(ev_uploaded); ev_uploaded = nullptr; }
     }
 };
 
-void xhe::set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) ctx->error = msg; else g_create_error = msg; }
+void xhe::set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->error = msg; } else g_create_error = msg; }
 
 // MSM over device-resident canonical scalars and affine-Niels records; result (8 words encoding, flag)
 // into d_result[0..8], d_result[8].
@@ -83,6 +88,11 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
 
 // B/H points, fixed-base tables, generators up to `cap` per side
 int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
+    {
+        std::shared_lock<std::shared_mutex> rd(ctx->tables_mu);
+        if (ctx->tables_ready && cap <= ctx->static_cap && std::min<u32>(ctx->static_cap, GEN_TABLE_CAP_MAX) <= ctx->gen_tab_cap) return 0;
+    }
+    std::unique_lock<std::shared_mutex> wr(ctx->tables_mu);      // waits for the verifications in flight: they read the tables
     hipStream_t st = ctx->stream;
     if (!ctx->tables_ready) {
         HIPCHK(ctx, ctx->base_pts.reserve(2 * 128));
@@ -140,7 +150,9 @@ xhe_ctx *xhe_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     xhe_ctx *ctx = new xhe_ctx();
     ctx->device = device_id;
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess && hipStreamCreate(&ctx->side[2]) == hipSuccess;
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess && hipStreamCreate(&ctx->side[2]) == hipSuccess &&
+              hipStreamCreate(&ctx->copy_stream) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_stage_free, hipEventDisableTiming) == hipSuccess && hipEventRecord(ctx->ev_stage_free, ctx->copy_stream) == hipSuccess;
     for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64, hipHostMallocDefault) == hipSuccess;
@@ -153,7 +165,7 @@ xhe_ctx *xhe_create(int device_id) {
 void xhe_destroy(xhe_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->copy_stream}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
                        &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
         b->release();
@@ -162,7 +174,8 @@ void xhe_destroy(xhe_ctx *ctx) {
     if (ctx->verdict_host) (void)hipHostFree(ctx->verdict_host);
     ctx->timer.release();
     for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) if (s) (void)hipStreamDestroy(s);
+    if (ctx->ev_stage_free) (void)hipEventDestroy(ctx->ev_stage_free);
+    for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->copy_stream}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -288,13 +301,40 @@ int32_t xhe_msm_vartime_static(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars3
 // ---- level 1 ----------------------------------------------------------------------------------------
 void xhe_batch_free(xhe_ctx *ctx, xhe_batch *b) {
     if (!b) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) {
+        // nothing may still read or write the batch's blocks when they go back to the pool: the copies of its upload, and the
+        // kernels of a verification that returned early on an error
+        (void)hipSetDevice(ctx->device);
+        if (b->ev_uploaded) (void)hipEventSynchronize(b->ev_uploaded);
+        for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
+    }
     b->release();
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->spare_mu); ctx->spare_host.trade_storage(b->hb); }
     delete b;
+}
+
+// Copies a list of (destination, source, bytes) on several host threads, in chunks of a few megabytes.
+struct copy_task { char *dst; const char *src; size_t bytes; };
+static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threads) {
+    constexpr size_t CHUNK = 4u << 20;
+    std::vector<copy_task> tasks;
+    size_t total = 0;
+    for (auto &t : tasks_in)
+        for (size_t o = 0; o < t.bytes; o += CHUNK) { tasks.push_back({t.dst + o, t.src + o, std::min(CHUNK, t.bytes - o)}); total += tasks.back().bytes; }
+    if (threads <= 1 || total < (8u << 20)) { for (auto &t : tasks) memcpy(t.dst, t.src, t.bytes); return; }
+    std::atomic<size_t> next(0);
+    auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= tasks.size()) break; memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes); } };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
 }
 
 // wait_for_copies = false leaves the table copies in flight on the main stream: the caller must synchronise that stream before
 // the next upload on this context (which reuses the pinned staging memory) - xhe_verify_batch does, by verifying.
+//
+// The device's byte buffer (records | account keys | ledger ciphertexts | multisig signer keys) depends on nothing the ingest
+// computes, so it is staged and sent by a helper thread while the ingest runs; the descriptor tables follow.
 static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
                                  xhe_verdict *structural, bool wait_for_copies) {
     if (!ctx || !offsets || !in || !batch_out || (n_txs && !records)) return XHE_E_ARG;
@@ -302,6 +342,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     HIPCHK(ctx, hipSetDevice(ctx->device));
     xhe_batch *B = new xhe_batch();
     host_batch &hb = B->hb;
+    hipStream_t st = ctx->copy_stream;
     auto t_start = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!getenv("XHE_UPLOAD_TIMES")) return;
@@ -309,40 +350,85 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         fprintf(stderr, "[xhe upload] %s %.3f ms\n", what, std::chrono::duration<double>(now - t_start).count() * 1e3);
         t_start = now;
     };
+    auto grow_stage = [&](size_t want) -> hipError_t {
+        if (ctx->stage_cap >= want) return hipSuccess;
+        if (ctx->stage) (void)hipHostFree(ctx->stage);
+        ctx->stage = nullptr; ctx->stage_cap = 0;
+        size_t cap = want + want / 4 + 4096;
+        hipError_t e = hipHostMalloc(&ctx->stage, cap, hipHostMallocDefault);
+        if (e == hipSuccess) ctx->stage_cap = cap;
+        return e;
+    };
+    const unsigned host_threads = ingest_thread_count();
+    { std::lock_guard<std::mutex> lk(ctx->spare_mu); hb.trade_storage(ctx->spare_host); }
+    // ---- the byte buffer: its own device block, staged and sent while the ingest runs ----
+    const u64 rec_bytes = offsets[n_txs], keys_base = (rec_bytes + 63) & ~63ull, cts_base = keys_base + 32 * in->n_accounts, signers_base = cts_base + 64 * in->n_balances;
+    const u64 n_signer_keys = in->n_multisig ? in->multisig_offsets[in->n_multisig] : 0;
+    const u64 bytes_len = signers_base + 32 * n_signer_keys + 64, bytes_region = (256 + bytes_len + 255) & ~255ull;      // the transcript's word gather may read a few bytes in front of a record
+    const bool early_bytes = bytes_region <= STAGE_MAX / 2;
+    if (hipEventCreateWithFlags(&B->ev_uploaded, hipEventDisableTiming) != hipSuccess) { set_error(ctx, "creating the batch's upload event failed"); delete B; return XHE_E_HIP; }
+    std::thread copier;
+    hipError_t copier_err = hipSuccess;
+    B->arena_bytes.pool = &ctx->pool;
+    if (early_bytes) {
+        hipError_t he = B->arena_bytes.reserve(bytes_region);
+        if (he == hipSuccess && ctx->stage_cap < bytes_region) { he = hipEventSynchronize(ctx->ev_stage_free); if (he == hipSuccess) he = grow_stage(bytes_region); }
+        if (he != hipSuccess) { set_error(ctx, std::string("allocating the batch's byte buffer: ") + hipGetErrorString(he)); B->release(); delete B; return XHE_E_HIP; }
+        B->bytes.point_at(B->arena_bytes.p, 256, bytes_len);
+        copier = std::thread([&, rec_bytes, keys_base, cts_base, signers_base, n_signer_keys, bytes_len]() {
+            (void)hipSetDevice(ctx->device);
+            (void)hipEventSynchronize(ctx->ev_stage_free);        // the previous upload's copies have left the staging memory
+            char *dst = (char *)ctx->stage + 256;
+            memset(ctx->stage, 0, 256);
+            memset(dst + rec_bytes, 0, keys_base - rec_bytes);
+            memset(dst + signers_base + 32 * n_signer_keys, 0, 64);
+            std::vector<copy_task> tasks = {{dst, (const char *)records, (size_t)rec_bytes}, {dst + keys_base, (const char *)in->account_keys, (size_t)(32 * in->n_accounts)},
+                                            {dst + cts_base, (const char *)in->balance_cts, (size_t)(64 * in->n_balances)},
+                                            {dst + signers_base, (const char *)in->multisig_signers, (size_t)(32 * n_signer_keys)}};
+            parallel_copy(tasks, host_threads >= 8 ? 4 : 1);
+            copier_err = hipMemcpyAsync(B->arena_bytes.p, ctx->stage, 256 + bytes_len, hipMemcpyHostToDevice, st);
+        });
+    }
+    auto join_copier = [&]() { if (copier.joinable()) copier.join(); };
     bool parsed = ingest_batch(hb, records, offsets, n_txs, *in);
     lap("ingest");
+    join_copier();
+    lap("byte buffer staged and enqueued");
+    if (hb.bad_ledger) {
+        set_error(ctx, "the ledger view is inconsistent (an account index out of range or multisig offsets that do not ascend from 0)");
+        (void)hipStreamSynchronize(st); B->release(); delete B; return XHE_E_ARG;
+    }
+    if (copier_err != hipSuccess) { set_error(ctx, std::string("uploading the batch's byte buffer: ") + hipGetErrorString(copier_err)); (void)hipStreamSynchronize(st); B->release(); delete B; return XHE_E_HIP; }
     if (structural) *structural = hb.structural;
     *batch_out = B;
     B->n_balances = in->n_balances; B->n_accounts = in->n_accounts;
     B->in_cts.assign(in->balance_cts, in->balance_cts + 64 * in->n_balances);
     B->in_nonces.assign(in->account_nonces, in->account_nonces + in->n_accounts);
-    lap("ledger copies");
-    if (!parsed) return 0;
+    if (!parsed) { (void)hipStreamSynchronize(st); return 0; }
     int32_t rc = ensure_tables(ctx, hb.nm_cap);
-    lap("tables");
     if (rc) { xhe_batch_free(ctx, B); *batch_out = nullptr; return rc; }
-    hipStream_t st = ctx->stream;
     std::vector<u32> emit_slot(hb.cms.size(), 0);
     for (auto &op : hb.ops) if (op.emit != 0xffffffffu) emit_slot[op.emit] = op.slot;
     std::vector<u32> group_txs; B->group_off.assign(17, 0);
     for (u32 lg = 0; lg < 16; lg++) { B->group_off[lg] = (u32)group_txs.size(); group_txs.insert(group_txs.end(), hb.lg_groups[lg].begin(), hb.lg_groups[lg].end()); }
     B->group_off[16] = (u32)group_txs.size();
-    // One device block for every uploaded table and one for the workspace; every buffer of the batch is a 256-byte aligned
-    // range of one of them.  The tables are assembled in the context's pinned staging memory and cross in one copy (in
-    // slices when they exceed it).
+    // One device block for the uploaded tables and one for the workspace; every buffer of the batch is a 256-byte aligned
+    // range of one of them.  The tables are assembled in the context's pinned staging memory (behind the byte buffer's region)
+    // and cross in one copy (in slices when they exceed it).
     B->arena_up.pool = &ctx->pool; B->arena_ws.pool = &ctx->pool;
     struct piece { dev_buf *buf; const void *src; size_t bytes, off; };
     std::vector<piece> ups, wss;
-    size_t up_total = 256, ws_total = 0;                 // the transcript's word gather may read a few bytes in front of a record
+    size_t up_total = 0, ws_total = 0;
     auto add = [](std::vector<piece> &list, size_t &total, dev_buf &b, const void *src, size_t bytes) {
         size_t sz = std::max<size_t>(bytes, 64);
         list.push_back({&b, src, bytes, total});
         total += (sz + 255) & ~(size_t)255;
     };
 #define UP(buf, vec) add(ups, up_total, B->buf, (vec).data(), (vec).size() * sizeof((vec)[0]))
-    {
-        // the byte buffer comes straight from the caller's arrays; the gaps between its parts are zero
+    if (!early_bytes) {
+        // too large for the early path: the byte buffer travels with the tables, straight from the caller's arrays; the gaps between its parts are zero
         static const u8 zeros[128] = {0};
+        up_total = 256;
         const size_t base = up_total;
         add(ups, up_total, B->bytes, nullptr, hb.bytes_len);
         auto part = [&](const void *src, size_t off, size_t bytes) { if (bytes) ups.push_back({nullptr, src, bytes, base + off}); };
@@ -386,33 +472,38 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     for (auto &pc : wss) pc.buf->point_at(B->arena_ws.p, pc.off, std::max<size_t>(pc.bytes, 64));
     lap("device blocks");
     {
-        const size_t want = std::min<size_t>(up_total, STAGE_MAX);
-        if (ctx->stage_cap < want) {
-            if (ctx->stage) (void)hipHostFree(ctx->stage);
-            ctx->stage = nullptr; ctx->stage_cap = 0;
-            size_t cap = want + want / 4 + 4096;
-            if ((he = hipHostMalloc(&ctx->stage, cap, hipHostMallocDefault)) != hipSuccess) return fail("allocating pinned staging memory", he);
-            ctx->stage_cap = cap;
+        if (!early_bytes && (he = hipEventSynchronize(ctx->ev_stage_free)) != hipSuccess) return fail("waiting for the staging memory", he);
+        // the tables' staging region lies behind the byte buffer's (whose copy may still be in flight)
+        size_t stage_off = early_bytes ? bytes_region : 0;
+        if (early_bytes && stage_off + std::min<size_t>(up_total, STAGE_MAX / 2) > ctx->stage_cap) {
+            // grow the staging memory: only once the byte buffer has left it
+            if ((he = hipStreamSynchronize(st)) != hipSuccess) return fail("uploading the batch's byte buffer", he);
+            stage_off = 0;
+            if ((he = grow_stage(bytes_region + std::min<size_t>(up_total, STAGE_MAX / 2))) != hipSuccess) return fail("allocating pinned staging memory", he);
+        } else if (!early_bytes) {
+            if ((he = grow_stage(std::min<size_t>(up_total, STAGE_MAX))) != hipSuccess) return fail("allocating pinned staging memory", he);
         }
+        const size_t room = ctx->stage_cap - stage_off;
         // slices of the concatenated layout: [lo, hi) in arena offsets
         size_t lo = 0;
         while (lo < up_total) {
-            size_t hi = std::min(up_total, lo + ctx->stage_cap);
+            size_t hi = std::min(up_total, lo + room);
+            std::vector<copy_task> tasks;
             for (auto &pc : ups) {
                 size_t a = std::max(pc.off, lo), b = std::min(pc.off + pc.bytes, hi);
-                if (a < b && pc.src) memcpy((char *)ctx->stage + (a - lo), (const char *)pc.src + (a - pc.off), b - a);
+                if (a < b && pc.src) tasks.push_back({(char *)ctx->stage + stage_off + (a - lo), (const char *)pc.src + (a - pc.off), b - a});
             }
-            if ((he = hipMemcpyAsync((char *)B->arena_up.p + lo, ctx->stage, hi - lo, hipMemcpyHostToDevice, st)) != hipSuccess) return fail("uploading the batch tables", he);
+            parallel_copy(tasks, host_threads);
+            if ((he = hipMemcpyAsync((char *)B->arena_up.p + lo, (char *)ctx->stage + stage_off, hi - lo, hipMemcpyHostToDevice, st)) != hipSuccess) return fail("uploading the batch tables", he);
             if (hi < up_total && (he = hipStreamSynchronize(st)) != hipSuccess) return fail("uploading the batch tables", he);      // the staging memory is reused
             lo = hi;
         }
+        if (up_total > room) wait_for_copies = true;
     }
     lap("tables staged and enqueued");
-    // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
-    HIPCHK(ctx, hipMemcpyAsync(B->pts.p, ctx->static_pts.p, 256 + 128ull * hb.nm_cap, hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(B->pts.as<u8>() + 256 + 128ull * hb.nm_cap, ctx->static_pts.as<u8>() + 256 + 128ull * ctx->static_cap, 128ull * hb.nm_cap,
-                               hipMemcpyDeviceToDevice, st));
-    if (wait_for_copies || up_total > ctx->stage_cap) HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stage_free, st));
+    HIPCHK(ctx, hipEventRecord(B->ev_uploaded, st));
+    if (wait_for_copies) HIPCHK(ctx, hipStreamSynchronize(st));
     lap("synchronize");
     return 0;
 }
@@ -439,9 +530,14 @@ int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
     const u32 n_txs = (u32)hb.n_txs, n_cm = (u32)hb.cms.size(), n_ops = (u32)hb.ops.size(), n_slots = (u32)hb.slot_of_used.size();
     stage_timer &tm = ctx->timer;
     tm.begin();
+    std::shared_lock<std::shared_mutex> tables_lock(ctx->tables_mu);
+    HIPCHK(ctx, hipStreamWaitEvent(st, B->ev_uploaded, 0));
     HIPCHK(ctx, tm.mark("setup", st));
     setup_jobs jobs;
     memset(jobs.seed, 0, 32); jobs.seed_dst = nullptr;
+    // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
+    jobs.copy(B->pts.p, ctx->static_pts.p, 64 + 32ull * hb.nm_cap);
+    jobs.copy(B->pts.as<u32>() + 64 + 32ull * hb.nm_cap, ctx->static_pts.as<u32>() + 64 + 32ull * ctx->static_cap, 32ull * hb.nm_cap);
     jobs.fill(B->ok.p, 0x01010101u, (hb.n_points + 3) / 4);
     jobs.copy(B->tx_err.p, B->apply_err0.p, std::max<u32>(n_txs, 1));
     jobs.fill(B->rp_err.p, 0, std::max<u32>(n_txs, 1));
@@ -542,6 +638,43 @@ int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     return rc;
 }
 
+// Transaction::verify_batch over several independent batches: a helper thread parses and uploads batch k + 1 (host work and
+// copies on the copy stream) while this thread verifies batch k, at most one batch ahead.
+int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_args *batches, xhe_verdict *verdicts) {
+    if (!ctx || (n_batches && (!batches || !verdicts))) return XHE_E_ARG;
+    for (uint64_t k = 0; k < n_batches; k++) if (!batches[k].offsets || !batches[k].in || !batches[k].rng_seed || (batches[k].n_txs && !batches[k].records)) return XHE_E_ARG;
+    std::vector<xhe_batch *> up(n_batches, nullptr);
+    std::vector<int32_t> up_rc(n_batches, 0);
+    std::mutex mu; std::condition_variable cv;
+    uint64_t uploaded = 0, verified = 0; bool stop = false;
+    std::thread uploader([&]() {
+        for (uint64_t k = 0; k < n_batches; k++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + 1; }); if (stop) return; }
+            const xhe_batch_args &a = batches[k];
+            up_rc[k] = batch_upload_impl(ctx, a.records, a.offsets, a.n_txs, a.in, &up[k], &verdicts[k], false);
+            { std::lock_guard<std::mutex> lk(mu); uploaded = k + 1; }
+            cv.notify_all();
+        }
+    });
+    int32_t rc = 0;
+    for (uint64_t k = 0; k < n_batches && rc == 0; k++) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); }
+        rc = up_rc[k];
+        if (rc == 0 && verdicts[k].accept) {
+            rc = xhe_batch_verify(ctx, up[k], &verdicts[k], batches[k].rng_seed);
+            if (rc == 0 && verdicts[k].accept && batches[k].out) rc = xhe_batch_read_ledger(ctx, up[k], batches[k].out);
+        }
+        if (up[k]) { xhe_batch_free(ctx, up[k]); up[k] = nullptr; }
+        { std::lock_guard<std::mutex> lk(mu); verified = k + 1; }
+        cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    uploader.join();
+    for (auto *b : up) if (b) xhe_batch_free(ctx, b);
+    return rc;
+}
+
 }  // extern "C"
 
 // The launch sequence of one verification.  Everything is enqueued on the context's stream; the only
@@ -562,10 +695,15 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     auto host_mark = [&](const char *what) {
         if (host_times) fprintf(stderr, "[xhe enqueue] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
     };
+    std::shared_lock<std::shared_mutex> tables_lock(ctx->tables_mu);
+    HIPCHK(ctx, hipStreamWaitEvent(st, B->ev_uploaded, 0));
     HIPCHK(ctx, tm.mark("setup", st));
     {
         setup_jobs jobs;
         memcpy(jobs.seed, seed, 32); jobs.seed_dst = B->seed.as<u32>();
+        // the static generators of this batch's point array: B, H, G_vec[nm_cap], H_vec[nm_cap]
+        jobs.copy(B->pts.p, ctx->static_pts.p, 64 + 32ull * hb.nm_cap);
+        jobs.copy(B->pts.as<u32>() + 64 + 32ull * hb.nm_cap, ctx->static_pts.as<u32>() + 64 + 32ull * ctx->static_cap, 32ull * hb.nm_cap);
         jobs.fill(B->ok.p, 0x01010101u, (hb.n_points + 3) / 4);
         jobs.copy(B->tx_err.p, B->tx_err0.p, std::max<u32>(n_txs, 1));
         jobs.fill(B->rp_err.p, 0, std::max<u32>(n_txs, 1));

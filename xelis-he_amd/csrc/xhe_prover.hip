@@ -17,6 +17,7 @@ extern "C" int32_t xhe_range_proofs_prove(xhe_ctx *ctx, uint64_t n, uint32_t m, 
     const u32 nm = 64 * m;
     u32 lg = 6; while ((1u << lg) < nm) lg++;
     if (int32_t rc = ensure_tables(ctx, nm)) return rc;
+    std::shared_lock<std::shared_mutex> tables_lock(ctx->tables_mu);
     if (ctx->gen_tab_cap < nm) { set_error(ctx, "xhe_range_proofs_prove: no fixed-base tables for this many generators"); return XHE_E_ARG; }
     const u64 proof_bytes = 32ull * (9 + 2 * lg);
     // proofs per chunk: the three scalar vectors (36 bytes per position each) stay below ~1.5 GiB; the grid's y dimension below 2^15

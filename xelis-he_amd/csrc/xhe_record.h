@@ -9,6 +9,15 @@
 
 namespace xhe {
 
+// Offsets (or lengths) of a record's transfers: transfer k lies at first + 320 k unless a transfer carries extra data, in
+// which case the table is spelled out.  Read like a vector: size(), [k].
+struct transfer_table {
+    u32 n = 0, first = 0, step = 320;
+    std::vector<u32> spelled;
+    size_t size() const { return n; }
+    u32 operator[](size_t k) const { return spelled.empty() ? first + step * (u32)k : spelled[k]; }
+};
+
 struct tx_record {
     u8 type, flags; u16 n_items, n_commitments, n_multisig, rp_len; u32 opaque_len;
     const u8 *base;            // start of the record
@@ -16,7 +25,7 @@ struct tx_record {
     u32 ms_off, sig_off;       // multisig entries, signature
     u32 payload_off, payload_len, rp_off, cm_off;
     u8 version; u64 fee, nonce;
-    std::vector<u32> transfer_off, transfer_len;   // Transfers: each asset,dest,C,D_s,D_r,[extra],proof(160)
+    transfer_table transfer_off, transfer_len;     // Transfers: each asset,dest,C,D_s,D_r,[extra],proof(160)
     bool has_multisig() const { return flags & 1; }
     const u8 *source() const { return base + pre_off + 1; }
     const u8 *pre() const { return base + pre_off; }
@@ -55,14 +64,15 @@ static inline bool record_parse(tx_record &t, const u8 *rec, u64 len) {
     if (t.type > 4 || (t.flags & ~1u) || rec_le16(rec + 14) != 0) return false;
     if (!t.has_multisig() && t.n_multisig) return false;
     u64 off = 16, payload = 0;
-    t.transfer_off.clear(); t.transfer_len.clear();
-    std::vector<u32> extra;
+    t.transfer_off = transfer_table(); t.transfer_len = transfer_table();
+    bool any_extra = false;
+    const u8 *extra_table = rec + 16;
     if (t.type == 0) {
         if (len < off + 4ull * t.n_items) return false;
         for (u32 i = 0; i < t.n_items; i++) {
-            u32 e = rec_le32(rec + off + 4 * i);
+            u32 e = rec_le32(extra_table + 4 * i);
             if ((e != 0 && e < 64) || e > (1u << 20)) return false;
-            extra.push_back(e); payload += 320 + e;
+            any_extra |= e != 0; payload += 320 + e;
         }
         off += 4ull * t.n_items;
         if (t.opaque_len) return false;
@@ -77,8 +87,15 @@ static inline bool record_parse(tx_record &t, const u8 *rec, u64 len) {
     const u8 *pre = rec + off;
     t.version = pre[0]; t.fee = rec_be64(pre + 33); t.nonce = rec_be64(pre + 41);
     t.payload_off = t.pre_off + 49; t.payload_len = (u32)payload;
-    u32 p = t.payload_off;
-    for (u32 e : extra) { t.transfer_off.push_back(p); t.transfer_len.push_back(320 + e); p += 320 + e; }
+    if (t.type == 0) {
+        t.transfer_off.n = t.transfer_len.n = t.n_items;
+        t.transfer_off.first = t.payload_off; t.transfer_off.step = 320;
+        t.transfer_len.first = 320; t.transfer_len.step = 0;
+        if (any_extra) {
+            u32 p = t.payload_off;
+            for (u32 i = 0; i < t.n_items; i++) { u32 e = rec_le32(extra_table + 4 * i); t.transfer_off.spelled.push_back(p); t.transfer_len.spelled.push_back(320 + e); p += 320 + e; }
+        }
+    }
     t.rp_off = t.payload_off + (u32)payload;
     t.cm_off = t.rp_off + t.rp_len;
     t.ms_off = t.pre_off + t.pre_len;

@@ -67,7 +67,7 @@ struct dev_xfer {
 };
 
 // one per point to decode
-struct dev_dec { u64 off; u32 early; u32 reserved; };      // early != 0: decoded ahead of the bulk (1: ledger scan input, 2: public key)
+struct dev_dec { u64 off; };      // byte offset of the 32-byte encoding
 
 // ledger scan: elementary operations sorted by (slot, order)
 struct dev_op {
