@@ -84,6 +84,10 @@ struct host_batch {
     std::vector<int64_t> multisig_set_by;  // per account
     std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
     pod_vec<u32> segs;                 // per-transaction segment tables
+    // Terms of the multiscalar check that share a point are merged before the bucket sort (their scalars add):
+    pod_vec<u32> merge_pairs;          // (kept term, absorbed term): a value commitment's sigma-proof term and its range-proof term
+    pod_vec<u32> key_terms;            // the terms on each account key (source and destination keys recur in every proof of an account's transactions) ...
+    std::vector<u32> key_group_off;    // ... as runs: group g = key_terms[key_group_off[g] .. key_group_off[g + 1])
     std::vector<u32> serial_txs;           // transactions whose transcript runs in the serial kernel
     std::vector<u32> tr_list;              // the others, sorted by template, each template padded to whole tiles of 64 (0xffffffff)
     std::vector<transcript_tile> tr_tiles; // one per 64 entries of tr_list
@@ -100,7 +104,7 @@ struct host_batch {
     void trade_storage(host_batch &o) {
         txs.trade_storage(o.txs); cms.trade_storage(o.cms); xfers.trade_storage(o.xfers); decs.trade_storage(o.decs); early_decs.trade_storage(o.early_decs);
         key_decs.trade_storage(o.key_decs); bulk_decs.trade_storage(o.bulk_decs); ops.trade_storage(o.ops); sigs.trade_storage(o.sigs); tx_err.trade_storage(o.tx_err);
-        apply_err.trade_storage(o.apply_err); segs.trade_storage(o.segs);
+        apply_err.trade_storage(o.apply_err); segs.trade_storage(o.segs); merge_pairs.trade_storage(o.merge_pairs); key_terms.trade_storage(o.key_terms);
     }
 };
 
@@ -307,6 +311,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     std::vector<u32> src_pos(n), src_keyslot(n), sig_base(n + 1), step_err(n, ERRKEY_NONE), tmpl_of_tx(n), rp_row(n, 0), hash_idx(n, NONE);
     std::vector<u32> cm_slot(n_cm, NONE), cm_local(n_cm, 0), xf_slot(n_xf, NONE), xf_local(n_xf, 0), xf_dest_pos(n_xf, NONE);
     std::vector<u8> cm_fresh(n_cm, 0), xf_fresh(n_xf, 0);
+    std::vector<u32> key_cnt(lv.n_accounts, 0), src_keylocal(n), xf_keylocal(n_xf, NONE);      // terms on each account's key, and where a transaction's come in its run
     struct ms_entry { u32 tx, k, key_pos, key_slot; u64 key_off; };
     std::vector<ms_entry> ms_entries;                  // co-signatures to verify, in transaction order
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_map;
@@ -332,6 +337,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             }
             // source key and its place among the distinct signing keys
             const u32 sa = src_acc[i];
+            if (sa != NONE) { src_keylocal[i] = key_cnt[sa]; key_cnt[sa] += A + T; }
             sig_base[i] = sigs; sigs++;
             if (sa != NONE) {
                 src_pos[i] = account_position(sa);
@@ -378,6 +384,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 const u32 x = xf_base[i] + k, da = xf_acc[x];
                 if (da == NONE) continue;
                 xf_dest_pos[x] = account_position(da);
+                xf_keylocal[x] = key_cnt[da]++;
                 if (xf_bal[x] == NONE) continue;
                 bool fresh; const u32 u = touch_slot(xf_bal[x], &fresh);
                 xf_slot[x] = u; xf_fresh[x] = fresh ? 1 : 0; xf_local[x] = ops_count[u]++;
@@ -432,6 +439,16 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
             rp_term[i] = term; term += 4 + 2 * lg + A + T;
         }
         hb.n_chal = chal; hb.static_term_off = term; hb.n_terms = term + hb.n_static;
+    }
+    // runs of terms per account key (accounts with a single term need no merging)
+    std::vector<u32> key_run(lv.n_accounts, NONE);
+    {
+        u32 o = 0;
+        hb.key_group_off.clear();
+        for (u64 a = 0; a < lv.n_accounts; a++) if (key_cnt[a] >= 2) { key_run[a] = o; hb.key_group_off.push_back(o); o += key_cnt[a]; }
+        hb.key_group_off.push_back(o);
+        hb.key_terms.resize(o);
+        hb.merge_pairs.resize(2ull * (n_cm + n_xf));
     }
     // co-signatures by transaction: ms_entries is in transaction order, so a transaction's entries follow its main signature
     std::vector<u32> ms_first(n + 1, 0);
@@ -511,6 +528,9 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 c.pt = put(c.off + 32, 0); put(c.off + 64, 0); put(c.off + 96, 0); put(c.off + 128, 0);
                 c.term_off = cm_term[i] + 7 * k;
                 c.src_ct_pt = hb.emit_base + 2 * ci; c.slot_pt = 0; c.first_touch = 0;
+                // C_new is the point of the proof's term 5 and of the range proof's value commitment k; P_source that of term 0
+                hb.merge_pairs[2ull * (ci + xf_base[i])] = c.term_off + 5; hb.merge_pairs[2ull * (ci + xf_base[i]) + 1] = rp_term[i] + 4 + 2 * lg + k;
+                if (sa != NONE && key_run[sa] != NONE) hb.key_terms[key_run[sa] + src_keylocal[i] + k] = c.term_off;
                 const u32 u = cm_slot[ci];
                 if (u == NONE) raise_state(errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
                 else {
@@ -537,6 +557,10 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 dev_xfer x{}; x.tx = (u32)i; x.idx = k; x.off = rec + t.transfer_off[k]; x.proof_off = x.off + t.transfer_len[k] - 160;
                 x.pt = xf_pt0 + 6 * k;
                 x.term_off = xf_term[i] + 8 * k;
+                // C is the point of the proof's term 0 and of value commitment A + k; P_source that of term 5, P_dest of term 2
+                hb.merge_pairs[2ull * (cm_base[i] + A + xi)] = x.term_off; hb.merge_pairs[2ull * (cm_base[i] + A + xi) + 1] = rp_term[i] + 4 + 2 * lg + A + k;
+                if (sa != NONE && key_run[sa] != NONE) hb.key_terms[key_run[sa] + src_keylocal[i] + A + k] = x.term_off + 5;
+                if (xf_keylocal[xi] != NONE && key_run[xf_acc[xi]] != NONE) hb.key_terms[key_run[xf_acc[xi]] + xf_keylocal[xi]] = x.term_off + 2;
                 if (xf_acc[xi] == NONE) {
                     x.dest_pt = put(x.off + 32, 0);
                     x.state_err = 1;

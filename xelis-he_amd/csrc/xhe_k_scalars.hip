@@ -362,6 +362,50 @@ __global__ void __launch_bounds__(256) k_static_terms(const u32 *__restrict__ gh
 }
 
 
+// ---- terms that share a point ----------------------------------------------------------------------------
+// thread per pair (kept, absorbed): the kept term takes the sum of the two scalars, the absorbed one becomes zero (a zero
+// scalar has no digits and never reaches the bucket sort)
+__global__ void __launch_bounds__(256) k_merge_pairs(const u32 *__restrict__ pairs, u32 n, u32 *__restrict__ scalars) {
+    wave_priority_high();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 keep = pairs[2 * i], drop = pairs[2 * i + 1];
+    const sc sum = sc_add(load_scalar_words(scalars + 8ull * keep), load_scalar_words(scalars + 8ull * drop));
+    store_scalar_words(scalars + 8ull * keep, sum);
+#pragma unroll
+    for (int k = 0; k < 8; k++) scalars[8ull * drop + k] = 0;
+}
+// wave per run of terms on one point: the first term takes the sum of the run's scalars, the others become zero
+__global__ void __launch_bounds__(64) k_merge_runs(const u32 *__restrict__ run_off, u32 n_runs, const u32 *__restrict__ terms, u32 *__restrict__ scalars) {
+    wave_priority_high();
+    const u32 g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n_runs) return;
+    const u32 lo = run_off[g], hi = run_off[g + 1];
+    sc acc = sc_zero(); u32 cnt = 0;
+    for (u32 k = lo + lane; k < hi; k += 64) {
+        const u32 t = terms[k];
+        acc = sc_add(acc, load_scalar_words(scalars + 8ull * t));
+        if (++cnt == 8) { acc = sc_reduce_mont(acc); cnt = 0; }
+        if (k != lo) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) scalars[8ull * t + j] = 0;
+        }
+    }
+    acc = sc_reduce_mont(acc);
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) {
+        sc o;
+#pragma unroll
+        for (int j = 0; j < 9; j++) o.v[j] = __shfl_down(acc.v[j], d, 64);
+        acc = sc_reduce_mont(sc_add(acc, o));
+    }
+    if (lane == 0 && hi > lo) store_scalar_words(scalars + 8ull * terms[lo], acc);
+}
+void launch_merge_terms(hipStream_t st, const u32 *pairs, u32 n_pairs, const u32 *run_off, u32 n_runs, const u32 *run_terms, u32 *scalars) {
+    if (n_pairs) hipLaunchKernelGGL(k_merge_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, scalars);
+    if (n_runs) hipLaunchKernelGGL(k_merge_runs, dim3(n_runs), dim3(64), 0, st, run_off, n_runs, run_terms, scalars);
+}
+
 void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a) {
     u32 blocks = (a.n_cm + 63) / 64 + (a.n_xf + 63) / 64 + 2 * ((a.n_txs + 63) / 64);          // two workgroups per 64 range proofs
     if (blocks) hipLaunchKernelGGL(k_proof_scalars, dim3(blocks), dim3(64), 0, st, a);

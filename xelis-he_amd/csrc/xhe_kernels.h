@@ -92,6 +92,9 @@ struct proof_scalar_args {
     const u32 *chal, *seed; u32 *scalars, *term_point, *rp_ctx, *gh, *rp_err;
 };
 void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a);
+// Terms that share a point: pairs (kept term, absorbed term), and runs of terms (run_off[n_runs + 1] into run_terms) whose
+// first term takes the run's sum; absorbed scalars become zero
+void launch_merge_terms(hipStream_t st, const u32 *pairs, u32 n_pairs, const u32 *run_off, u32 n_runs, const u32 *run_terms, u32 *scalars);
 void launch_sc_sum_partial(hipStream_t st, u32 blocks, const u32 *in, u32 n, u32 classes, u32 *out);
 // A workgroup takes rows_per_thread transactions of an lg-group, rp_matrix_slots(lg) of them side by side, and writes one row of
 // partial column sums per slot: part[ceil(n_rows / rows_per_thread) * slots][2 * 2^lg], summed by launch_rp_colsum

@@ -40,7 +40,7 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
-    dev_buf bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
+    dev_buf merge_pairs, key_terms, key_group_off, bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     dev_buf arena_up, arena_ws, arena_bytes;   // the blocks every buffer above is a range of: uploaded tables, workspace, the byte buffer
@@ -48,7 +48,7 @@ struct xhe_batch {
     hipEvent_t ev_uploaded = nullptr;   // fires on the copy stream when every table of the batch has arrived
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
+        for (dev_buf *b : {&merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
             b->release();
@@ -441,6 +441,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     }
     UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(bulk_decs, hb.bulk_decs); UP(sig_keys, hb.sig_keys); UP(ops, hb.ops); UP(sigs, hb.sigs);
     UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
+    UP(merge_pairs, hb.merge_pairs); UP(key_terms, hb.key_terms); UP(key_group_off, hb.key_group_off);
     UP(tx_err0, hb.tx_err); UP(apply_err0, hb.apply_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
     u64 n_slots = hb.slot_of_used.size();
@@ -789,6 +790,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     {
         proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
         launch_proof_scalars(st, pa);
+        // terms on one point become one term: a value commitment's sigma and range-proof terms, every term on an account's key
+        static const bool merge_terms = !(getenv("XHE_MERGE_TERMS") && getenv("XHE_MERGE_TERMS")[0] == '0');
+        if (merge_terms) launch_merge_terms(st, B->merge_pairs.as<u32>(), (u32)(hb.merge_pairs.size() / 2), B->key_group_off.as<u32>(), (u32)hb.key_group_off.size() - 1, B->key_terms.as<u32>(), scalars);
     }
     // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
     // parts).  With fixed-base tables their whole contribution is evaluated on side 0 while the main stream
@@ -848,6 +852,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     // Slow path (a proof is wrong): decide between GenericProof and RangeProof as the reference orders them
     // (verify.rs:500-514) with the sigma-only multiscalar check.
     {
+        // the merged scalars mix sigma-proof and range-proof terms: the sigma-only check runs on the scalars as the proofs give them
+        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
+        launch_proof_scalars(st, pa);
         u32 n_sig_terms = hb.sigma_terms;
         dev_buf s2, tp2, r2;
         HIPCHK(ctx, s2.reserve(32ull * (n_sig_terms + 2))); HIPCHK(ctx, tp2.reserve(4ull * (n_sig_terms + 2))); HIPCHK(ctx, r2.reserve(64));
