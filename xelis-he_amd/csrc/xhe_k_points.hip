@@ -1,5 +1,6 @@
 // Point kernels: batched ristretto decode/encode, constant tables (B, H, Bulletproofs generators, fixed-base
 // tables), decode of a batch's point list, and the error-precedence kernels.
+#include <stdlib.h>
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 
@@ -83,8 +84,12 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 // ---- decode ----------------------------------------------------------------------------------------
 static constexpr u32 DECODE_MAX_BLOCKS = 512;
 // A pass over the n listed entries of decs[] (the points the ledger scan waits for, the public keys, or all the others).
-__global__ void __launch_bounds__(256, 2) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
-                                                        u32 *__restrict__ pts, u8 *__restrict__ ok, u32 background) {
+// OCC = wavefronts per SIMD the kernel is compiled for: 2 (256 registers) or 4 (128 registers, a little spilling outside the
+// inverse square root's squaring chain): alone the two run within 2 % of each other, but two 256-register wavefronts fill a
+// SIMD's register file and keep every other kernel of the verification off it until they end.
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_decode_list(const u8 *__restrict__ bytes, const dev_dec *__restrict__ decs, const u32 *__restrict__ list, u32 n, u32 pt_base,
+                                                          u32 *__restrict__ pts, u8 *__restrict__ ok, u32 background) {
     if (background) wave_priority_mid(); else wave_priority_upper();  // the first two head the ledger scan and the signatures; the bulk only has to beat the accumulation
     for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
         u32 i = list[g];
@@ -174,10 +179,15 @@ void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases
     if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background) {
-    // at most two wavefronts per SIMD (512 workgroups of four on 256 CUs): the decode is the widest kernel of a verification and
-    // runs beside the critical path, whose few long-running wavefronts must find free slots the moment they are launched
+    // a bounded grid (grid-stride loop): the decode is the widest kernel of a verification and runs beside the critical path,
+    // whose few long-running wavefronts must find free slots the moment they are launched
+    static const u32 max_blocks = getenv("XHE_DECODE_MAX_BLOCKS") ? (u32)strtoul(getenv("XHE_DECODE_MAX_BLOCKS"), nullptr, 10) : DECODE_MAX_BLOCKS;
+    static const bool occ2 = getenv("XHE_DECODE_OCC") && getenv("XHE_DECODE_OCC")[0] == '2';
     u32 blocks = grid_for(n, 256);
-    if (n) hipLaunchKernelGGL(k_decode_list, dim3(blocks < DECODE_MAX_BLOCKS ? blocks : DECODE_MAX_BLOCKS), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok, background ? 1u : 0u);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (!n) return;
+    if (occ2) hipLaunchKernelGGL(k_decode_list<2>, dim3(blocks), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok, background ? 1u : 0u);
+    else hipLaunchKernelGGL(k_decode_list<4>, dim3(blocks), dim3(256), 0, st, bytes, decs, list, n, pt_base, pts, ok, background ? 1u : 0u);
 }
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);

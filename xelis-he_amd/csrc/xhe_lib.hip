@@ -737,7 +737,9 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     //   main     transcripts -> proof scalars -> multiscalar check -> verdict
     //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
     //   side 1   every other point of the batch (public keys included) -> signature points + hashing -> end of the signature hashes
-    hipStream_t s0 = ctx->side[0], s1 = ctx->side[1];
+    // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
+    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
+    hipStream_t s0 = one_stream ? st : ctx->side[0], s1 = one_stream ? st : ctx->side[1];
     HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
@@ -748,7 +750,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     // The host needs several microseconds per launch, so the order below is also the order in which the work can start: the
     // decodes first (the bulk decode is the longest side job), the ledger scan (which waits for its inputs anyway) after them.
     const bool own_sig_stream = n_txs >= sig_stream_min_txs();
-    hipStream_t ssig = own_sig_stream ? ctx->side[2] : s1;
+    hipStream_t ssig = one_stream ? st : (own_sig_stream ? ctx->side[2] : s1);
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
     HIPCHK(ctx, tm.open("decode_first", s0));
     launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
