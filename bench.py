@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--cpu-prover", action="store_true", help="generate the range proofs of the synthetic batch on the CPU (same bytes, slower)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo reduces through host memory, for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (only with --backend gloo)")
+    ap.add_argument("--split-one-batch", action="store_true",
+                    help="with --gpus N: rank 0 generates ONE batch of N x --txs transactions, cuts it along its account groups (xhe_partition_batch) and hands "
+                         "every rank its shard; a step verifies the shards and MIN-reduces the 8-byte verdict key (BASELINE's one-batch-over-8-GPUs shape); "
+                         "the default is one independent batch per rank")
     return ap.parse_args()
 
 
@@ -98,6 +102,61 @@ def term_counts(txs, transfers, mixed):
         dyn_terms = (txs // 16) * (2 * 24 + 4 * 35 + 4 * 54 + 2 * 24 + 2 * 34 + 2 * 35)
         static_terms = 2 + 2 * 256
     return dyn_terms, static_terms
+
+
+class FlatBatch:
+    """A batch held as plain buffers (what a rank receives in --split-one-batch mode): the fields Resident and the library read."""
+
+    def __init__(self, records, offsets, ledger):
+        from xelis_he_amd.api import LedgerView
+        self.records, self.n_txs = records, len(offsets) - 1
+        self.offsets = (ctypes.c_uint64 * len(offsets))(*offsets)
+        self._keep = ledger
+        n_acc, n_bal = len(ledger["keys"]) // 32, len(ledger["assets"]) // 32
+        self._nonces = (ctypes.c_uint64 * max(n_acc, 1))()
+        self._bal_acc = (ctypes.c_uint32 * max(n_bal, 1))(*ledger["balance_account"])
+        v = LedgerView()
+        v.n_accounts, v.account_keys, v.account_nonces = n_acc, ledger["keys"], self._nonces
+        v.n_balances, v.balance_account, v.balance_assets, v.balance_cts = n_bal, self._bal_acc, ledger["assets"], ledger["cts"]
+        self._view = v
+        self.view = ctypes.pointer(v)
+
+    def close(self):
+        pass
+
+
+def split_one_batch(args, dist, rank, world, engine):
+    """Rank 0 generates the whole batch, cuts it and scatters the shards; returns this rank's FlatBatch and its transactions' global indices."""
+    from xelis_he_amd import sharding
+    from xelis_he_amd.api import SyntheticBatch
+    parts = None
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        big = SyntheticBatch(args.txs * world, args.transfers, min(args.senders * world, args.txs * world), seed=b"bench-split", threads=args.gen_threads,
+                             engine=None if args.cpu_prover else engine)
+        offs = [big.offsets[i] for i in range(big.n_txs + 1)]
+        recs = [big.records[offs[i]:offs[i + 1]] for i in range(big.n_txs)]
+        shards = sharding.partition(recs, world)
+
+        class RawView(ctypes.Structure):
+            _fields_ = [("n_accounts", ctypes.c_uint64), ("account_keys", ctypes.c_void_p), ("account_nonces", ctypes.c_void_p), ("n_balances", ctypes.c_uint64),
+                        ("balance_account", ctypes.c_void_p), ("balance_assets", ctypes.c_void_p), ("balance_cts", ctypes.c_void_p), ("n_multisig", ctypes.c_uint64),
+                        ("multisig_account", ctypes.c_void_p), ("multisig_threshold", ctypes.c_void_p), ("multisig_offsets", ctypes.c_void_p), ("multisig_signers", ctypes.c_void_p)]
+        rv = ctypes.cast(big.view, ctypes.POINTER(RawView)).contents
+        bal_acc = ctypes.cast(rv.balance_account, ctypes.POINTER(ctypes.c_uint32))
+        ledger = {"keys": ctypes.string_at(rv.account_keys, 32 * rv.n_accounts), "assets": ctypes.string_at(rv.balance_assets, 32 * rv.n_balances),
+                  "cts": ctypes.string_at(rv.balance_cts, 64 * rv.n_balances), "balance_account": [bal_acc[i] for i in range(rv.n_balances)]}
+        parts = []
+        for s in shards:
+            o = [0]
+            for i in s:
+                o.append(o[-1] + len(recs[i]))
+            parts.append((b"".join(recs[i] for i in s), o, s, ledger))
+        big.close()
+    got = [None]
+    dist.scatter_object_list(got, parts, src=0)
+    blob, o, idx, ledger = got[0]
+    return FlatBatch(blob, o, ledger), idx
 
 
 class Resident:
@@ -140,6 +199,9 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
+        # the process has four hardware queues: with RCCL's own stream beside the library's, the signatures stay on the decode
+        # stream (three kernel streams) instead of taking a fourth
+        os.environ.setdefault("XHE_SIG_STREAM_MIN_TXS", str(1 << 30))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
@@ -163,7 +225,12 @@ def main():
     if mixed:
         args.txs -= args.txs % 16
     gen_engine = None if (mixed or args.cpu_prover) else engine
-    batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed, engine=gen_engine)
+    split = args.split_one_batch and dist is not None and not mixed
+    global_index = None
+    if split:
+        batch, global_index = split_one_batch(args, dist, rank, world, engine)
+    else:
+        batch = SyntheticBatch(args.txs, args.transfers, senders, seed=b"bench-rank-%d" % rank, threads=args.gen_threads, mixed=mixed, engine=gen_engine)
     gen_s = time.time() - t0
     res = Resident(engine, lib, batch)
 
@@ -172,7 +239,13 @@ def main():
 
     def step(i):
         ok = res.step(i)
-        if dist is not None:
+        if dist is not None and split:
+            # one batch over all ranks: the MIN of the shards' 8-byte verdict keys is the batch's verdict (accept = the largest key)
+            from xelis_he_amd import sharding
+            flag.fill_(sharding.verdict_key(bool(ok), res.verdict.err_code, res.verdict.first_bad_tx, global_index))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = 1 if int(flag.item()) == sharding.ACCEPT_KEY else 0
+        elif dist is not None:
             flag.fill_(ok)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # AND of the per-shard accept bits
             ok = int(flag.item())
@@ -329,7 +402,8 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": ("%d-tx mixed batch per GPU (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers), %d account groups" % (args.txs, args.txs // 16)) if mixed
                        else "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
-                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": "tx-sharded x%d, RCCL MIN all-reduce of accept bits" % args.gpus,
+                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": ("one %d-tx batch cut along account groups into %d shards, RCCL MIN all-reduce of the 8-byte verdict key" % (args.txs * args.gpus, args.gpus)) if split
+                       else "tx-sharded x%d (one batch per rank), RCCL MIN all-reduce of accept bits" % args.gpus,
                        "inputs": "resident in HBM (xhe_batch_upload before the timed region); see end_to_end for the call from host buffers"},
             "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline, "end_to_end": end_to_end, "secondary": secondary,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},

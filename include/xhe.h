@@ -149,6 +149,24 @@ typedef struct xhe_batch_args {
 } xhe_batch_args;
 int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_args *batches, xhe_verdict *verdicts);
 
+/* ---- several GPUs: the replica model of the reference's bench (benches/tx.rs:252-343), applied to ONE batch ------------------
+ *
+ * xhe_verify_batch_sharded is xhe_verify_batch over n_ctx contexts (one per GPU; the same device may appear twice): the batch is
+ * cut along the connected components of its account graph (a transaction depends on every earlier one that touches its accounts,
+ * verify.rs:301-341), every shard is verified by its own context against the same ledger snapshot on a thread of its own, and the
+ * verdicts combine by the reference's precedence (first failing transaction in batch order, verify.rs:492-498, then GenericProof,
+ * then RangeProof, verify.rs:500-514).  verdict, first_bad_tx (an index into the whole batch) and `out` are those of the
+ * single-context call.  xhe_partition_batch exposes the cut (shard_of_tx[i] in [0, n_shards); returns 1 and the index when a record
+ * is malformed), xhe_verdict_key / xhe_verdict_from_key the 64-bit key whose MIN over the shards is the batch's verdict: a
+ * process-per-GPU driver all-reduces that one word (RCCL, MIN) instead of calling xhe_verify_batch_sharded. */
+int32_t xhe_partition_batch(const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, uint32_t n_shards, uint32_t *shard_of_tx,
+                            int64_t *first_malformed);
+int32_t xhe_verify_batch_sharded(xhe_ctx *const *ctxs, uint32_t n_ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
+                                 const xhe_ledger_view *in, const xhe_ledger_out *out, xhe_verdict *verdict, const uint8_t rng_seed[32]);
+/* global_index[k] = position in the whole batch of the shard's k-th transaction (n_local entries) */
+uint64_t xhe_verdict_key(const xhe_verdict *shard_verdict, const uint64_t *global_index, uint64_t n_local);
+void xhe_verdict_from_key(uint64_t key, xhe_verdict *verdict);
+
 /* The same verification on a batch already resident in HBM: xhe_batch_upload parses, checks and
  * uploads the records and the ledger once; xhe_batch_verify runs only GPU work plus a 16-byte
  * read-back.  xhe_batch_read_ledger copies the resulting ledger out after an accepting verify. */

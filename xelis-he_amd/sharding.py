@@ -13,13 +13,34 @@ host tensors.
 import ctypes
 
 from . import codes
+from ._capi import XheError, load_library
 
 ACCEPT_KEY = (1 << 63) - 1
-_AGGREGATE_STAGE = {codes.ERR_GENERIC_PROOF: 1, codes.ERR_RANGE_PROOF: 2}
+
+
+def _lib():
+    lib = load_library()
+    if not getattr(lib, "_shard_ready", False):
+        lib.xhe_partition_batch.restype = ctypes.c_int32
+        lib.xhe_partition_batch.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.POINTER(ctypes.c_int64)]
+        lib.xhe_verdict_key.restype = ctypes.c_uint64
+        lib.xhe_verdict_key.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64]
+        lib.xhe_verdict_from_key.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        lib._shard_ready = True
+    return lib
+
+
+class MalformedRecord(Exception):
+    """A record of the batch does not parse: the verdict is XHE_ERR_MALFORMED at .index, whatever else the batch holds."""
+
+    def __init__(self, index):
+        super().__init__("record %d is malformed" % index)
+        self.index = index
 
 
 def tx_accounts(record: bytes):
-    """(source, [destinations]) of a flat transaction record (include/xhe.h)."""
+    """(source, [destinations]) of a flat transaction record (include/xhe.h); the record must have parsed (partition checks)."""
     ttype, n_items = record[0], int.from_bytes(record[2:4], "little")
     pre = 16 + (4 * n_items if ttype == codes.TX_TRANSFERS else 0)
     source = record[pre + 1:pre + 33]
@@ -33,63 +54,44 @@ def tx_accounts(record: bytes):
     return source, dests
 
 
-def tx_weight(record: bytes):
-    """Dynamic multiscalar terms of a transaction: 7 per source commitment, 8 per transfer, 4 + 2 lg + m of the range proof."""
-    n_items = int.from_bytes(record[2:4], "little") if record[0] == codes.TX_TRANSFERS else 0
-    n_cm = int.from_bytes(record[4:6], "little")
-    m = 1
-    while m < n_cm + n_items:
-        m *= 2
-    lg = 6 + m.bit_length() - 1
-    return 7 * n_cm + 8 * n_items + 4 + 2 * lg + m
-
-
 def partition(records, world_size):
-    """Transaction indices per rank: connected components of the account graph, heaviest first onto the
-    lightest rank; indices ascending inside a rank (batch order is preserved)."""
-    parent = {}
-
-    def find(x):
-        while parent.setdefault(x, x) != x:
-            parent[x] = parent[parent[x]]
-            x = parent[x]
-        return x
-
+    """Transaction indices per rank (xhe_partition_batch): connected components of the account graph, heaviest first onto the
+    lightest rank; indices ascending inside a rank (batch order is preserved).  Every record is parsed by the library first:
+    a malformed one raises MalformedRecord with the smallest such index."""
+    n = len(records)
+    blob = b"".join(records)
+    offs = [0]
     for r in records:
-        src, dests = tx_accounts(r)
-        a = find(src)
-        for d in dests:
-            b = find(d)
-            if a != b:
-                parent[b] = a
-    comps = {}
-    for i, r in enumerate(records):
-        c = comps.setdefault(find(tx_accounts(r)[0]), [0, []])
-        c[0] += tx_weight(r)
-        c[1].append(i)
-    shards, load = [[] for _ in range(world_size)], [0] * world_size
-    for w, idx in sorted(comps.values(), key=lambda c: (-c[0], c[1][0])):
-        k = min(range(world_size), key=lambda j: (load[j], j))
-        shards[k].extend(idx)
-        load[k] += w
-    return [sorted(s) for s in shards]
+        offs.append(offs[-1] + len(r))
+    offsets = (ctypes.c_uint64 * (n + 1))(*offs)
+    shard_of = (ctypes.c_uint32 * max(n, 1))()
+    bad = ctypes.c_int64(-1)
+    rc = _lib().xhe_partition_batch(blob, offsets, n, world_size, shard_of, ctypes.byref(bad))
+    if rc == 1:
+        raise MalformedRecord(int(bad.value))
+    if rc != 0:
+        raise XheError("xhe_partition_batch failed: %d" % rc)
+    shards = [[] for _ in range(world_size)]
+    for i in range(n):
+        shards[shard_of[i]].append(i)
+    return shards
 
 
 def verdict_key(accept, err_code, first_bad_local, shard):
-    """The 63-bit key a rank contributes to the MIN all-reduce."""
-    if accept:
-        return ACCEPT_KEY
-    stage = _AGGREGATE_STAGE.get(err_code, 0)
-    index = shard[first_bad_local] if (stage == 0 and first_bad_local >= 0) else 0
-    return (stage << 60) | (index << 8) | (err_code & 0xff)
+    """The 63-bit key a rank contributes to the MIN all-reduce (xhe_verdict_key): per-transaction errors order by their index in
+    the whole batch, then GenericProof, then RangeProof."""
+    from .api import Verdict
+    v = Verdict(1 if accept else 0, int(err_code), int(first_bad_local))
+    g = (ctypes.c_uint64 * max(len(shard), 1))(*shard)
+    return int(_lib().xhe_verdict_key(ctypes.byref(v), g, len(shard)))
 
 
 def decode_key(key):
-    """(accept, err_code, first_bad_tx) of a reduced key."""
-    if key == ACCEPT_KEY:
-        return True, codes.OK, -1
-    stage = key >> 60
-    return False, key & 0xff, ((key >> 8) & ((1 << 52) - 1)) if stage == 0 else -1
+    """(accept, err_code, first_bad_tx) of a reduced key (xhe_verdict_from_key)."""
+    from .api import Verdict
+    v = Verdict()
+    _lib().xhe_verdict_from_key(ctypes.c_uint64(key), ctypes.byref(v))
+    return bool(v.accept), int(v.err_code), int(v.first_bad_tx)
 
 
 def all_reduce_min(value, dist, device=None):
@@ -100,20 +102,20 @@ def all_reduce_min(value, dist, device=None):
 
 
 def merge_ledger_bytes(own_cts, owned_mask, dist, device=None):
-    """Resulting ciphertexts of every ledger slot: each slot is written by at most one rank (its account's
-    component lives there); slots no rank owns come back as zero bytes and keep their input value."""
-    import torch
+    """Resulting ciphertexts of every ledger slot: each slot is written by at most one rank (its account's component lives
+    there), so the ranks exchange only the slots they own -- (slot index, 64 bytes) per touched slot, not the whole ledger.
+    Returns (bytes of all slots with the owned ones filled in, zero elsewhere; per slot the number of ranks that own it)."""
     n = len(owned_mask)
-    t = torch.zeros(64 * n + n, dtype=torch.int32)
-    raw = torch.frombuffer(bytearray(own_cts[:64 * n]), dtype=torch.uint8).to(torch.int32).view(n, 64) if n else torch.zeros(0, 64, dtype=torch.int32)
-    mask = torch.tensor([1 if m else 0 for m in owned_mask], dtype=torch.int32)
-    t[:64 * n] = (raw * mask[:, None]).reshape(-1)
-    t[64 * n:] = mask
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    t = t.cpu()
-    return bytes(t[:64 * n].to(torch.uint8).tolist()), [int(x) for x in t[64 * n:]]
+    mine = [i for i, m in enumerate(owned_mask) if m]
+    payload = (mine, b"".join(own_cts[64 * i:64 * i + 64] for i in mine))
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, payload)
+    merged, count = bytearray(64 * n), [0] * n
+    for idx, blob in gathered:
+        for k, i in enumerate(idx):
+            merged[64 * i:64 * i + 64] = blob[64 * k:64 * k + 64]
+            count[i] += 1
+    return bytes(merged), count
 
 
 def verify_batch_sharded(verify_fn, txs, ledger, dist, device=None):
@@ -125,7 +127,10 @@ def verify_batch_sharded(verify_fn, txs, ledger, dist, device=None):
     """
     from .api import LedgerOut
     rank, world = dist.get_rank(), dist.get_world_size()
-    shards = partition([t.record for t in txs], world)
+    try:
+        shards = partition([t.record for t in txs], world)
+    except MalformedRecord as e:              # every rank sees the same records: the same verdict everywhere, nothing to reduce
+        return False, codes.ERR_MALFORMED, e.index
     mine = shards[rank]
     f = ledger.flatten()
     out_cts = (ctypes.c_uint8 * max(64 * len(f["slots"]), 1))()
