@@ -1,6 +1,6 @@
 // Schnorr signature verification (/root/reference/src/elgamal.rs:38-65): accept iff
 // e == SHA3-512(pk || msg || enc(s*H - e*P)) mod l.  Four parts:
-//   key tables     four lanes per distinct signing key (k_sig_key_tables): the multiples 0..8 of 2^(64 j) P, j < 4 -- a key
+//   key tables     a wavefront per distinct signing key (k_sig_key_tables): the multiples 0..8 of 2^(64 j) P, j < 4 -- a key
 //                  signs every transaction of its account's chain, so the 192 doublings are paid once per key (batches with
 //                  few signatures per key skip this part and use k_sig_point_absorb_own_table);
 //   absorb         thread per signature: absorbs the whole 72-byte blocks of pk || msg into a Keccak state
@@ -16,6 +16,7 @@
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_quad.h"
+#include "xhe_wide.h"
 
 namespace xhe {
 
@@ -89,32 +90,39 @@ __device__ __forceinline__ qd_point qd_add_cached(const qd_point &p, const fe &c
 
 static constexpr u32 SIG_QUADS = 16;          // signatures per 64-thread workgroup
 
-// Table of one key per quad of lanes: for j < SIG_KEY_POS the multiples 0..8 of 2^(64 j) P in cached form.  Keys sign many
+// Table of one key per wavefront (xhe_wide.h: a lane per limb, a row of lanes per coordinate): for j < SIG_KEY_POS the multiples
+// 0..8 of 2^(64 j) P as the multiplicands (Y - X, Y + X, Z, 2d T) the point kernel's quads add from.  Keys sign many
 // transactions of a batch (an account's whole chain), and with the table a signature costs 64 doublings + 64 additions instead
-// of 256 + 72.  (An undecodable key left the identity in pts[]; k_sig_final reports it.)
+// of 256 + 72.  The 192 doublings of a key are one dependent chain, so its length in instructions is what this kernel costs:
+// ~170 per doubling in this form against ~420 on a quad of lanes.  (An undecodable key left the identity in pts[];
+// k_sig_final reports it.)
 __global__ void __launch_bounds__(64) k_sig_key_tables(const u32 *__restrict__ sig_keys, u32 n_keys, const u32 *__restrict__ pts, u32 *__restrict__ key_tab) {
-    const u32 lane = threadIdx.x, role = lane & 3;
-    for (u32 group = blockIdx.x; group * SIG_QUADS < n_keys; group += gridDim.x) {
-        const u32 kq = group * SIG_QUADS + (lane >> 2);
-        const u32 k = kq < n_keys ? kq : n_keys - 1;         // spare quads repeat the last key and store nothing
+    const wd_lane L = wd_lane_init();
+    const u32 d2 = wd_const_d2(L);
+    // the chain is the head of the signatures' critical path and one wavefront per SIMD wide: let it issue ahead of the
+    // bulk kernels it shares the SIMD with
+    __builtin_amdgcn_s_setprio(3);
+    for (u32 k = blockIdx.x; k < n_keys; k += gridDim.x) {
         ge_niels pn = ge_niels_load(pts + 32ull * sig_keys[k]);
-        qd_point cur = qd_from_ge(ge_from_niels_affine(pn), role);
+        wd_point cur = wd_from_ge(ge_from_niels_affine(pn), L);
 #pragma unroll 1
         for (u32 j = 0; j < SIG_KEY_POS; j++) {
-            qd_point m = qd_identity(role);
-            u32 *dst = key_tab + ((u64)k * SIG_KEY_POS + j) * 9 * SIG_KEY_ENTRY_WORDS + 10 * role;
+            const wd_cached step = wd_to_cached(cur, L);
+            wd_point m; m.v = ((L.row == 1 || L.row == 2) && L.k == 0) ? 1u : 0u;          // the identity (0, 1, 1, 0)
+            u32 *dst = key_tab + ((u64)k * SIG_KEY_POS + j) * 9 * SIG_KEY_ENTRY_WORDS + 10 * L.row + L.k;
 #pragma unroll 1
             for (u32 mult = 0; mult < 9; mult++) {
-                fe c = qd_to_cached(m, role);
-                if (kq < n_keys) {
-#pragma unroll
-                    for (int l = 0; l < 10; l++) dst[mult * SIG_KEY_ENTRY_WORDS + l] = c.v[l];
-                }
-                m = qd_add(m, cur, role);
+                u32 x, y, z, t;
+                wd_rows(m.v, x, y, z, t);
+                u32 td = wd_mul(t, d2, L);
+                u32 sums = wd_weak_reduce(L.row == 0 ? y + (L.p2 - x) : y + x, L);
+                u32 entry = L.row < 2 ? sums : L.row == 2 ? z : td;
+                if (L.live) dst[mult * SIG_KEY_ENTRY_WORDS] = entry;
+                if (mult < 8) m = wd_add(m, step, L);
             }
             if (j + 1 < SIG_KEY_POS) {
 #pragma unroll 1
-                for (u32 d = 0; d < 256 / SIG_KEY_POS; d++) cur = qd_double(cur, role);
+                for (u32 d = 0; d < 256 / SIG_KEY_POS; d++) cur = wd_double(cur, L);
             }
         }
     }
@@ -293,8 +301,7 @@ __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, 
 
 void launch_sig_key_tables(hipStream_t st, const u32 *sig_keys, u32 n_keys, const u32 *pts, u32 *key_tab) {
     if (!n_keys) return;
-    u32 blocks = grid_for(n_keys, SIG_QUADS);
-    hipLaunchKernelGGL(k_sig_key_tables, dim3(blocks < SIG_MAX_WAVES ? blocks : SIG_MAX_WAVES), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
+    hipLaunchKernelGGL(k_sig_key_tables, dim3(n_keys < SIG_MAX_WAVES ? n_keys : SIG_MAX_WAVES), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
 }
 void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state) {
     if (!n) return;
