@@ -191,9 +191,13 @@ void xhe_batch_free(xhe_ctx *ctx, xhe_batch *batch);
  *   XHE_DEBUG_GENERATORS  B, B_blinding (= H), then the first k generators G_i and the first k H_i of BP_GENS
  *                         (src/proofs.rs:19-22) as the kernels hold them, re-encoded: 32 bytes each, k = (cap / 32 - 2) / 2
  *                         capped at the batch's generator count.
+ *   XHE_DEBUG_STATIC_SCALARS  after xhe_batch_verify: the scalars of B, B_blinding, G_0.., H_0.. in the merged check (sums over
+ *                         all range proofs of the batch, each proof weighted with the verifier's random factor), 32 bytes
+ *                         each, canonical; 2 + 2 * (the batch's generator count) values.
  * Returns the number of 32-byte values written, or < 0. */
 #define XHE_DEBUG_CHALLENGES 1
 #define XHE_DEBUG_GENERATORS 2
+#define XHE_DEBUG_STATIC_SCALARS 3
 int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *batch, int32_t what, uint8_t *out, uint64_t cap_bytes);
 
 /* Per-stage GPU time of the last xhe_batch_verify / xhe_msm_vartime on this context, measured with HIP

@@ -251,6 +251,15 @@ __device__ __forceinline__ sc prf_scalar(const u32 *__restrict__ seed8, u32 doma
     for (int i = 0; i < 8; i++) { w[2 * i] = (u32)st[i]; w[2 * i + 1] = (u32)(st[i] >> 32); }
     return sc_from_wide_words(w);
 }
+// A 128-bit factor (never zero): what batch verification needs for a 2^-128 error bound.  A term whose scalar is the bare
+// factor or its negative (the proofs' first commitments Y_0) then has digits in the lower half of the windows only, and the
+// bucket sort and the accumulation skip the rest.
+__device__ __forceinline__ sc prf_scalar_128(const u32 *__restrict__ seed8, u32 domain, u64 index) {
+    u64 st[25];
+    prf_state(st, seed8, domain, index);
+    u32 w[8] = {(u32)st[0] | 1u, (u32)(st[0] >> 32), (u32)st[1], (u32)(st[1] >> 32), 0, 0, 0, 0};
+    return sc_from_words(w);
+}
 __device__ __forceinline__ void prf_scalar_pair(sc &first, sc &second, const u32 *__restrict__ seed8, u32 domain, u64 index) {
     u64 st[25];
     prf_state(st, seed8, domain, index);

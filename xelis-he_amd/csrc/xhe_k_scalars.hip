@@ -15,7 +15,7 @@ __device__ __forceinline__ void sigma_cm_terms(u32 i, const u8 *__restrict__ byt
     const u8 *p = bytes + c.off;
     sc ch_c = load_scalar_words(chal + 8ull * (d.chal_off + 2 * c.idx)), ch_w = load_scalar_words(chal + 8ull * (d.chal_off + 2 * c.idx + 1));
     sc z_s = load_scalar_bytes(p + 160), z_x = load_scalar_bytes(p + 192), z_r = load_scalar_bytes(p + 224);
-    sc bf = prf_scalar(seed, 1, i);
+    sc bf = prf_scalar_128(seed, 1, i);
     sc ww = sc_mul(ch_w, ch_w);
     sc w_bf = sc_mul(ch_w, bf), ww_bf = sc_mul(ww, bf);
     sc neg_bf = sc_neg(bf), neg_w_bf = sc_neg(w_bf), neg_ww_bf = sc_neg(ww_bf);
@@ -43,7 +43,7 @@ __device__ __forceinline__ void sigma_xf_terms(u32 i, const u8 *__restrict__ byt
     u32 cbase = d.chal_off + 2 * d.n_commitments + 2 * x.idx;
     sc ch_c = load_scalar_words(chal + 8ull * cbase), ch_w = load_scalar_words(chal + 8ull * (cbase + 1));
     sc z_r = load_scalar_bytes(pr + 96), z_x = load_scalar_bytes(pr + 128);
-    sc bf = prf_scalar(seed, 2, i);
+    sc bf = prf_scalar_128(seed, 2, i);
     sc w_bf = sc_mul(ch_w, bf), ww_bf = sc_mul(sc_mul(ch_w, ch_w), bf);
     sc neg_bf = sc_neg(bf), neg_w_bf = sc_neg(w_bf), neg_ww_bf = sc_neg(ww_bf);
     u32 *s = scalars + 8ull * x.term_off;
@@ -97,9 +97,6 @@ __global__ void __launch_bounds__(256) k_sc_sum_partial(const u32 *__restrict__ 
 //   H_i:  rho' z - rho b U       prod_(b not in i) Y2[b] U2[b]
 //               + rho z^2 U^2    prod_(b in i) E[b]  prod_(b not in i) Y2[b],   E[b] = 2^(2^b) (b < 6), z^(2^(b-6)) (b >= 6)
 // per-transaction context for the matrix kernel, Montgomery limbs (9 words each)
-static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_H2 = 3, RPC_COEF_H3 = 4, RPC_U2 = 5 /* 16 */, RPC_YU = 21 /* 16 */,
-                     RPC_Y2 = 37 /* 16 */, RPC_E = 53 /* 16 */;
-static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 
 // Two threads per proof (in different workgroups, so control flow stays uniform): `side` 0 computes the scalars of the
 // L_j and R_j and the per-bit tables of the context, side 1 everything else.  Both need y^(nm-1) and prod u_j^2 and

@@ -1,6 +1,7 @@
 // Host-callable launchers of the gfx950 kernels.  Each xhe_k_*.hip translation unit defines its kernels
 // and the launchers declared here; xhe_lib.hip only sequences them on the context's stream.
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime_api.h>
 #include "xhe_verify_types.h"
 
@@ -86,6 +87,10 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
 void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts);
 // proof scalars
 static constexpr u32 RPC_SCALARS = 69;    // Montgomery-limb scalars in a transaction's range-proof context
+// positions in that context (the products they enter: see the table above rp_prep_terms in xhe_k_scalars.hip)
+static constexpr u32 RPC_NEG_RHO_Z = 0, RPC_RHO_Z = 1, RPC_COEF_G = 2, RPC_COEF_H2 = 3, RPC_COEF_H3 = 4, RPC_U2 = 5 /* 16 */, RPC_YU = 21 /* 16 */,
+                     RPC_Y2 = 37 /* 16 */, RPC_E = 53 /* 16 */;
+static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 // sigma-proof terms, range-proof terms and the per-transaction range-proof context in one launch
 struct proof_scalar_args {
     const u8 *bytes; const dev_tx *txs; const dev_cm *cms; const dev_xfer *xfers; u32 n_cm, n_xf, n_txs;
@@ -103,6 +108,28 @@ static inline u32 rp_rows_per_thread(u64 n_rows, u32 lg) { u64 r = n_rows / 512;
 static inline u64 rp_matrix_part_rows(u64 n_rows, u32 lg) { u32 rpt = rp_rows_per_thread(n_rows, lg); return ((n_rows + rpt - 1) / rpt) * rp_matrix_slots(lg); }
 void launch_rp_matrix(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 rows_per_thread, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u32 *part);
 void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm_cap, u32 *acc);
+// The same column sums as an integer matrix product on the matrix cores (xhe_k_rpgemm.hip), for groups with enough transactions
+// to fill it.  A group is processed in chunks of chunk_rows transactions: dig holds one chunk's digit tables, bins the partial
+// diagonal sums of its slices, rho_part RP_GEMM_RHO_PARTS scalars.
+static constexpr u32 RP_GEMM_RHO_PARTS = 64;
+struct rp_gemm_plan { u32 l, h, n_lo, n_hi, per, chunk_rows, kb_per_slice, max_slices; u64 dig_bytes, bins_bytes; };
+static inline rp_gemm_plan rp_gemm_plan_for(u64 n_rows, u32 lg) {
+    rp_gemm_plan p;
+    p.l = (lg + 1) / 2; p.h = lg - p.l; p.n_lo = 1u << p.l; p.n_hi = 1u << p.h; p.per = p.n_lo + p.n_hi;
+    const u64 bytes_per_tx = 3ull * p.per * 32;
+    u64 chunk = std::min<u64>(32768, ((256ull << 20) / bytes_per_tx) & ~63ull);
+    chunk = std::min<u64>(chunk, (n_rows + 63) & ~63ull);
+    p.chunk_rows = (u32)std::max<u64>(chunk, 64);
+    const u32 kb = p.chunk_rows / 32, tiles = (p.n_hi / 8) * (p.n_lo / 8);
+    // enough workgroups to fill the device, and at most 64 k-blocks per slice (the diagonal sums are 32-bit)
+    u32 slices = std::max<u32>((kb + 63) / 64, std::min<u32>(kb, (1024 + 3 * tiles - 1) / (3 * tiles)));
+    p.kb_per_slice = (kb + slices - 1) / slices;
+    p.max_slices = (kb + p.kb_per_slice - 1) / p.kb_per_slice;
+    p.dig_bytes = bytes_per_tx * p.chunk_rows;
+    p.bins_bytes = 3ull * p.max_slices * (256ull << lg);
+    return p;
+}
+void launch_rp_gemm(hipStream_t st, const u32 *group_txs, u32 n_rows, u32 lg, const u32 *rp_ctx, const u32 *rp_err, u8 *dig, int *bins, u32 *rho_part, u32 nm_cap, u32 *acc);
 void launch_static_terms(hipStream_t st, const u32 *gh_sums, u32 n_parts, const u32 *acc, u32 nm_cap, u32 static_term_off, u32 *scalars, u32 *term_point);
 
 

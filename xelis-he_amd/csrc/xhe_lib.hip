@@ -41,7 +41,8 @@ struct xhe_batch {
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
     dev_buf merge_pairs, key_terms, key_group_off, bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
-    dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, tx_err, rp_err, ms_hash;
+    u64 rp_gemm_min_rows = ~0ull;
+    dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, rp_dig, rp_bins, rp_rho, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     dev_buf arena_up, arena_ws, arena_bytes;   // the blocks every buffer above is a range of: uploaded tables, workspace, the byte buffer
     std::vector<u32> group_off;   // per lg: offset into group_txs
@@ -49,7 +50,7 @@ struct xhe_batch {
     bool verified_ok = false;
     void release() {
         for (dev_buf *b : {&merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
-                           &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
+                           &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &rp_dig, &rp_bins, &rp_rho, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
             b->release();
         if (ev_uploaded) { (void)hipEventDestroy(ev_uploaded); ev_uploaded = nullptr; }
@@ -335,6 +336,10 @@ static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threa
 //
 // The device's byte buffer (records | account keys | ledger ciphertexts | multisig signer keys) depends on nothing the ingest
 // computes, so it is staged and sent by a helper thread while the ingest runs; the descriptor tables follow.
+// Range-proof column sums: groups of at least this many transactions go through the matrix cores (xhe_k_rpgemm.hip), smaller
+// ones through the element-by-element kernel, whose cost has no fixed part.  XHE_RP_GEMM_MIN_ROWS overrides the threshold
+// (1: always the matrix path; a huge value: never); it is read when a batch is uploaded and kept with the batch.
+static u64 rp_gemm_min_rows() { const char *e = getenv("XHE_RP_GEMM_MIN_ROWS"); return e ? strtoull(e, nullptr, 10) : 512ull; }
 static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
                                  xhe_verdict *structural, bool wait_for_copies) {
     if (!ctx || !offsets || !in || !batch_out || (n_txs && !records)) return XHE_E_ARG;
@@ -456,13 +461,16 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
     RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.sigs.size()); RS(sig_r, 128ull * hb.sigs.size()); RS(sig_tab, 4ull * SIG_KEY_TABLE_WORDS * hb.sig_keys.size());
     // partial column sums of the range-proof scalar matrix: one row per tile of transactions
+    // (groups with many transactions take the matrix-core path instead: digit tables of one chunk, partial diagonal sums)
     {
-        u64 worst = 0;
+        u64 worst = 0, dig = 0, bins = 0;
+        B->rp_gemm_min_rows = rp_gemm_min_rows();
         for (u32 lg = 6; lg < 16; lg++) {
             u64 rows = hb.lg_groups[lg].size(); if (!rows) continue;
-            worst = std::max<u64>(worst, rp_matrix_part_rows(rows, lg) * (72ull << lg));
+            if (rows >= B->rp_gemm_min_rows) { const rp_gemm_plan p = rp_gemm_plan_for(rows, lg); dig = std::max(dig, p.dig_bytes); bins = std::max(bins, p.bins_bytes); }
+            else worst = std::max<u64>(worst, rp_matrix_part_rows(rows, lg) * (72ull << lg));
         }
-        RS(rp_mat, worst);
+        RS(rp_mat, worst); RS(rp_dig, dig); RS(rp_bins, bins); RS(rp_rho, 36ull * RP_GEMM_RHO_PARTS);
     }
 #undef RS
     auto fail = [&](const char *what, hipError_t e) { set_error(ctx, std::string(what) + ": " + hipGetErrorString(e)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; };
@@ -622,6 +630,12 @@ int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *B, int32_t what, uint8_t *
             ristretto_encode(out + 32 * i, p);
         }
         return (int64_t)(2 + 2 * k);
+    }
+    if (what == XHE_DEBUG_STATIC_SCALARS) {
+        // scalars of B, H, G_vec[nm_cap], H_vec[nm_cap] as the last xhe_batch_verify of this batch left them (canonical, 32 bytes each)
+        const u64 n = std::min<u64>(2 + 2ull * hb.nm_cap, cap_bytes / 32);
+        if (n) HIPCHK(ctx, hipMemcpy(out, B->scalars.as<u8>() + 32ull * hb.static_term_off, 32 * n, hipMemcpyDeviceToHost));
+        return (int64_t)n;
     }
     return XHE_E_ARG;
 }
@@ -809,6 +823,11 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     for (u32 lg = 6; lg < 16; lg++) {
         u32 rows = (u32)hb.lg_groups[lg].size();
         if (!rows) continue;
+        if (rows >= B->rp_gemm_min_rows) {
+            launch_rp_gemm(ss, B->group_txs.as<u32>() + B->group_off[lg], rows, lg, B->rp_ctx.as<u32>(), rp_err, B->rp_dig.as<u8>(), B->rp_bins.as<int>(), B->rp_rho.as<u32>(), hb.nm_cap,
+                           B->rp_acc.as<u32>());
+            continue;
+        }
         launch_rp_matrix(ss, B->group_txs.as<u32>() + B->group_off[lg], rows, rp_rows_per_thread(rows, lg), lg, B->rp_ctx.as<u32>(), rp_err, B->rp_mat.as<u32>());
         launch_rp_colsum(ss, B->rp_mat.as<u32>(), (u32)rp_matrix_part_rows(rows, lg), lg, hb.nm_cap, B->rp_acc.as<u32>());
     }
