@@ -13,6 +13,7 @@
 //                  reduces mod l and compares with e.
 // A multisig co-signature hashes the 32-byte BLAKE3 digest of the pre-image instead of the message
 // (/root/reference/src/tx/verify.rs:259-292): it has no whole block before R, so only the last kernel hashes.
+#include <stdlib.h>
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_quad.h"
@@ -21,9 +22,16 @@
 namespace xhe {
 
 static constexpr u32 SIG_RATE_WORDS = 9;      // SHA3-512: 72-byte rate
-// The signatures run in the background of the main path: at most one wavefront per SIMD of each kernel stays resident
-// (grid-stride beyond that), so that their registers never keep a main-path workgroup from being placed.
-static constexpr u32 SIG_MAX_WAVES = 1024;
+// The signatures run in the background of the main path: their kernels stay resident with a bounded number of wavefronts
+// (grid-stride beyond that) and within 128 vector registers, the size of the bulk decode's wavefronts, so that a signature
+// wavefront takes the place of exactly one of the four decode wavefronts of its SIMD.  Measured on the 100 000 x 8-transfer
+// batch: 165 registers / 1024 wavefronts 24.8 ms per step, 165 / 256 22.9 ms, 128 / 1024 22.8 ms, 128 / 512 22.3 ms, 128 / 256
+// 22.6 ms (with fewer the signatures end after everything else).  XHE_SIG_MAX_WAVES overrides the bound.
+static constexpr u32 SIG_MAX_WAVES_DEFAULT = 512;
+static u32 sig_max_waves() {
+    static const u32 v = [] { const char *e = getenv("XHE_SIG_MAX_WAVES"); u32 x = e ? (u32)strtoul(e, nullptr, 10) : 0; return x >= 64 && x <= 65536 ? x : SIG_MAX_WAVES_DEFAULT; }();
+    return v;
+}
 
 // byte j of pk || msg (msg = the digest for a co-signature)
 struct sig_stream {
@@ -246,7 +254,7 @@ __device__ __forceinline__ void sig_point_work_own_table(u32 block, u32 n_blocks
 
 // One launch for the two independent parts: workgroups [0, point_blocks) compute the points, the others absorb the
 // message blocks (both grid-stride over their share).
-__global__ void __launch_bounds__(64) k_sig_point_absorb(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sig_point_absorb(u32 point_blocks, const u8 *__restrict__ bytes, const dev_sig *__restrict__ sigs, u32 n,
                                                          const u32 *__restrict__ key_tab, const u32 *__restrict__ htab, u32 *__restrict__ r_out, u64 *__restrict__ state) {
     if (blockIdx.x < point_blocks) sig_point_work(blockIdx.x, point_blocks, bytes, sigs, n, key_tab, htab, r_out);
     else sig_absorb_work(blockIdx.x - point_blocks, gridDim.x - point_blocks, bytes, sigs, n, state);
@@ -301,13 +309,13 @@ __global__ void __launch_bounds__(64) k_sig_final(const u8 *__restrict__ bytes, 
 
 void launch_sig_key_tables(hipStream_t st, const u32 *sig_keys, u32 n_keys, const u32 *pts, u32 *key_tab) {
     if (!n_keys) return;
-    hipLaunchKernelGGL(k_sig_key_tables, dim3(n_keys < SIG_MAX_WAVES ? n_keys : SIG_MAX_WAVES), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
+    hipLaunchKernelGGL(k_sig_key_tables, dim3(n_keys < sig_max_waves() ? n_keys : sig_max_waves()), dim3(64), 0, st, sig_keys, n_keys, pts, key_tab);
 }
 void launch_sig_point_absorb(hipStream_t st, const u8 *bytes, const dev_sig *sigs, u32 n, const u32 *key_tab, const u32 *pts, const u32 *htab, u32 *r_out, u64 *state) {
     if (!n) return;
     u32 pb = grid_for(n, SIG_QUADS), ab = grid_for(n, 64);
-    if (pb > SIG_MAX_WAVES) pb = SIG_MAX_WAVES;
-    if (ab > SIG_MAX_WAVES) ab = SIG_MAX_WAVES;
+    if (pb > sig_max_waves()) pb = sig_max_waves();
+    if (ab > sig_max_waves()) ab = sig_max_waves();
     if (key_tab) hipLaunchKernelGGL(k_sig_point_absorb, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, key_tab, htab, r_out, state);
     else hipLaunchKernelGGL(k_sig_point_absorb_own_table, dim3(pb + ab), dim3(64), 0, st, pb, bytes, sigs, n, pts, htab, r_out, state);
 }
