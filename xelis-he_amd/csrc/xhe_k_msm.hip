@@ -239,8 +239,9 @@ __global__ void __launch_bounds__(256) k_msm_scan(const u32 *__restrict__ hist, 
 }
 
 // workgroup (tile, window): LDS counters start at the tile's first position inside each bucket's segment
+// (entry_point, nullable: the entry names the term's point record instead of the term, see msm_launch)
 __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
-                                                     const u32 *__restrict__ offsets, u32 *__restrict__ sorted, u64 sorted_cap) {
+                                                     const u32 *__restrict__ offsets, u32 *__restrict__ sorted, u64 sorted_cap, const u32 *__restrict__ entry_point, u32 n_points) {
     wave_priority_high();
     extern __shared__ u32 cnt[];
     const u32 tile = blockIdx.x, w = blockIdx.y;
@@ -259,7 +260,9 @@ __global__ void __launch_bounds__(512) k_msm_scatter(const unsigned short *__res
             u32 d = dv[j], a = d & 0x7fffu;
             if (a) {
                 u32 pos = atomicAdd(&cnt[a - 1], 1u);
-                if (pos < sorted_cap) sorted[pos] = (u32)(k0 + (u64)j * blockDim.x) | ((d & 0x8000u) << 16);
+                u32 name = (u32)(k0 + (u64)j * blockDim.x);
+                if (entry_point) { name = entry_point[name]; if (name >= n_points) name = 0x7fffffffu; }
+                if (pos < sorted_cap) sorted[pos] = name | ((d & 0x8000u) << 16);
             }
         }
     }
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(512) k_msm_coarse_hist(const unsigned short *_
     for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = cnt[b];
 }
 __global__ void __launch_bounds__(512) k_msm_coarse_scatter(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
-                                                            const u32 *__restrict__ coarse_off, u32 *__restrict__ tmp, u64 cap) {
+                                                            const u32 *__restrict__ coarse_off, u32 *__restrict__ tmp, u64 cap, const u32 *__restrict__ entry_point, u32 n_points) {
     wave_priority_high();
     extern __shared__ u32 cnt[];
     const u32 tile = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits, fine_mask = (1u << p.fine_bits) - 1;
@@ -309,7 +312,9 @@ __global__ void __launch_bounds__(512) k_msm_coarse_scatter(const unsigned short
             u32 d = dv[j], a = d & 0x7fffu;
             if (a) {
                 u32 pos = atomicAdd(&cnt[(a - 1) >> p.fine_bits], 1u);
-                if (pos < cap) tmp[pos] = (u32)(k0 + (u64)j * blockDim.x) | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
+                u32 name = (u32)(k0 + (u64)j * blockDim.x);
+                if (entry_point) { name = entry_point[name]; if (name >= n_points) name = 0xffffffu; }
+                if (pos < cap) tmp[pos] = name | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
             }
         }
     }
@@ -399,7 +404,8 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
 }
 
 // Thread per chunk [t*M, (t+1)*M) of the bucket-sorted entries.  term_point (nullable): term index ->
-// record index in niels[]; n_points bounds the gather.  chunk_sums[2t] = partial sum of the bucket that
+// record index in niels[]; n_points bounds the gather.  (When the sort already wrote record indices, msm_launch passes no
+// map and the record count as n.)  chunk_sums[2t] = partial sum of the bucket that
 // began before the chunk, chunk_sums[2t+1] = partial sum of the bucket that continues after it.
 __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
                                                            const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets, u32 M,
@@ -665,6 +671,11 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
                       const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user) {
 #define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
+    // With a term -> point map, the sort's entries name the point record directly when the index fits the entry (31 bits, 24 in
+    // the two-pass format): the scatter reads the map in term order (coalesced), and the accumulate stage goes from entry to
+    // record without a random 4-byte gather per entry in between.
+    const bool direct = d_term_point && n_points < (p.fine_bits ? (1ull << 24) - 1 : (1ull << 31) - 1);
+    const u32 *entry_point = direct ? d_term_point : nullptr;
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
     hipError_t e;
     const u32 tiles = (u32)msm_sort_tiles(n, p), lds_bytes = p.B * 4;
@@ -679,7 +690,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs);          // segs is free until the reduce stage
         hipLaunchKernelGGL(k_msm_scan, dim3(scan_tiles), dim3(256), 0, st, ws.hist, (u32)n_buckets, ws.segs, ws.offsets);
         MARK("msm_scatter");
-        hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist, ws.offsets, ws.sorted, sorted_cap, entry_point, (u32)n_points);
     } else {
         msm_plan q = p; q.B = p.B >> p.fine_bits;      // the coarse bins play the buckets' part in the prefix and scan kernels
         const u32 n_bins = p.W * q.B;
@@ -687,13 +698,13 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
         MARK("msm_scan");
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(1), dim3(1024), 0, st, ws.tile_hist, n_bins, q.B, tiles, ws.coarse);
         MARK("msm_scatter");
-        hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap);
+        hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap, entry_point, (u32)n_points);
         hipLaunchKernelGGL(k_msm_fine_sort, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);
     }
     MARK("msm_wait_points");
     for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
     MARK("msm_accumulate");
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, n, d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, direct ? n_points : n, direct ? (const u32 *)nullptr : d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
                        ws.buckets, ws.chunk_sums);
     MARK("msm_merge");
     hipLaunchKernelGGL(k_msm_merge, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.offsets, (u32)n_buckets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
