@@ -11,7 +11,7 @@ n, t = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 lib = _lib()
 eng = xelis_he_amd.Engine(0)
-batch = SyntheticBatch(n, t, min(1024, n), seed=b"e2e", threads=16)
+batch = SyntheticBatch(n, t, min(1024, n), seed=b"e2e", threads=16, engine=eng)
 v = Verdict()
 for i in range(reps):
     t0 = time.perf_counter()
