@@ -524,7 +524,10 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
 int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t rng_seed[32]) {
     if (!ctx || !B || !verdict || !rng_seed) return XHE_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return batch_verify_impl(ctx, B, verdict, rng_seed);
+    const int32_t rc = batch_verify_impl(ctx, B, verdict, rng_seed);
+    // an error return leaves in the middle of the launch sequence: nothing of it may still run when the caller goes on
+    if (rc != 0) for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
+    return rc;
 }
 
 // Transaction::apply_without_verify for every transaction of the batch in order: the ledger arithmetic alone
@@ -878,6 +881,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         launch_proof_scalars(st, pa);
         u32 n_sig_terms = hb.sigma_terms;
         dev_buf s2, tp2, r2;
+        struct release_on_exit { dev_buf &a, &b, &c; ~release_on_exit() { a.release(); b.release(); c.release(); } } temporaries{s2, tp2, r2};   // also on an early error return
         HIPCHK(ctx, s2.reserve(32ull * (n_sig_terms + 2))); HIPCHK(ctx, tp2.reserve(4ull * (n_sig_terms + 2))); HIPCHK(ctx, r2.reserve(64));
         HIPCHK(ctx, hipMemcpyAsync(s2.p, scalars, 32ull * n_sig_terms, hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(tp2.p, term_point, 4ull * n_sig_terms, hipMemcpyDeviceToDevice, st));
@@ -889,7 +893,6 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false, false);
         u32 h2[16];
         if (rc == 0) { hipError_t e = hipMemcpyAsync(h2, r2.p, 64, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipStreamSynchronize(st); if (e != hipSuccess) rc = XHE_E_HIP; }
-        s2.release(); tp2.release(); r2.release();
         if (rc) return rc;
         if (!h2[8]) { *verdict = {0, XHE_ERR_GENERIC_PROOF, -1}; return 0; }
     }
