@@ -293,6 +293,8 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                     "traffic": None if mixed else measured_traffic(args.txs, args.transfers), "kernel": "k_msm_accumulate", "kernel_ms": round(acc_ms, 4),
                     "algorithmic_bytes": algo_bytes, "terms": dyn_terms + static_terms}
+        roofline["traffic_source"] = ("FETCH_SIZE + WRITE_SIZE of the kernel per launch, newest committed rocprofv3 --pmc passes of this workload under profiles/"
+                                      if roofline["traffic"] is not None else "unmeasured for this workload (no committed --pmc pass)")
 
     # The kernel is bound by VALU issue, not by HBM: wave-instructions per launch (PMC) / launch time against the chip's vector
     # issue rate, one wave-instruction per 2 cycles per SIMD (a 64-wide wavefront on a SIMD-32 takes two passes).  The kernel's
