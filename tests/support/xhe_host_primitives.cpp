@@ -127,7 +127,7 @@ extern "C" double xt_ingest(const u8 *records, const u64 *offsets, u64 n, const 
     host_batch hb;
     bool ok = ingest_batch(hb, records, offsets, n, *view);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    out_counts[0] = ok; out_counts[1] = hb.n_points; out_counts[2] = hb.n_terms; out_counts[3] = hb.sigs.size();
-    out_counts[4] = hb.ops.size(); out_counts[5] = hb.tr_tiles.size(); out_counts[6] = hb.n_chal; out_counts[7] = hb.tr_plan.stream_words;
+    out_counts[0] = ok; out_counts[1] = hb.n_points; out_counts[2] = hb.n_terms; out_counts[3] = hb.n_sigs;
+    out_counts[4] = hb.n_ops; out_counts[5] = hb.tr_tiles.size(); out_counts[6] = hb.n_chal; out_counts[7] = hb.tr_plan.stream_words;
     return sec;
 }

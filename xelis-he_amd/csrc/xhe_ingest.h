@@ -65,29 +65,30 @@ struct host_batch {
     u64 n_txs = 0;
     u64 bytes_len = 0, rec_bytes = 0, n_signer_keys = 0;      // device byte buffer: records || account keys || balance cts || multisig signers || spare
     u64 keys_base = 0, cts_base = 0, signers_base = 0;
-    pod_vec<dev_tx> txs;
-    pod_vec<dev_cm> cms;
-    pod_vec<dev_xfer> xfers;
-    pod_vec<dev_dec> decs;             // decode list; point index = n_static + position: per-transaction blocks, then the shared points
-    pod_vec<u32> early_decs;           // positions in decs[] of the points the ledger scan reads (ledger and transfer ciphertexts)
-    pod_vec<u32> key_decs;             // positions in decs[] of the public keys the signatures are checked against
-    pod_vec<u32> bulk_decs;            // positions in decs[] of every other point
+    // What the ordered walk decides, per transaction, transfer and commitment: the device expands these records into the
+    // descriptors, decode lists, ledger operations and signature descriptors (k_expand_descriptors, xhe_k_expand.hip).
+    pod_vec<expand_tx> ex_txs;
+    pod_vec<expand_xf> ex_xfs;
+    pod_vec<expand_cm> ex_cms;
+    std::vector<expand_ms> ex_mss;         // co-signatures, in transaction order
+    std::vector<dev_dec> shared_decs;      // points shared between transactions (account keys, ledger ciphertexts, signer keys): decs[] behind the blocks
+    std::vector<u32> shared_early, shared_key;     // their positions, by decode list
+    std::vector<u32> slot_pos, slot_base;  // per used slot: position of its initial C (D = +1); first of its operations (n_slots + 1 entries)
+    std::vector<u32> emit_slot;            // per commitment: the used slot its emitted ciphertext belongs to
     std::vector<u32> sig_keys;             // point index of every distinct key a signature of the batch is checked against
-    pod_vec<dev_op> ops;               // sorted by slot
-    pod_vec<dev_sig> sigs;
-    pod_vec<u32> tx_err;               // host-detected precedence keys (ERRKEY_NONE if none)
-    pod_vec<u32> apply_err;            // the subset apply_without_verify knows: unknown account / asset only
+    // sizes of what the device writes
+    u32 n_cm = 0, n_xf = 0, n_sigs = 0, n_ops = 0, n_decs = 0, n_early = 0, n_key = 0, n_bulk = 0, n_segs = 0, n_key_terms = 0;
+    u32 blk_end = 0, early_end = 0, key_end = 0;       // where the shared points start in decs[] and in the two lists
     std::vector<u32> slot_of_used;         // used slot -> ledger balance index
-    std::vector<u32> slot_last_op;         // used slot -> index of its last op in ops[]
     std::vector<u32> ms_hash_tx;           // transactions whose pre-image BLAKE3 digest is needed
     std::vector<std::vector<u32>> lg_groups;   // transactions by lg (index = lg)
     std::vector<int64_t> multisig_set_by;  // per account
     std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
-    pod_vec<u32> segs;                 // per-transaction segment tables
-    // Terms of the multiscalar check that share a point are merged before the bucket sort (their scalars add):
-    pod_vec<u32> merge_pairs;          // (kept term, absorbed term): a value commitment's sigma-proof term and its range-proof term
-    pod_vec<u32> key_terms;            // the terms on each account key (source and destination keys recur in every proof of an account's transactions) ...
-    std::vector<u32> key_group_off;    // ... as runs: group g = key_terms[key_group_off[g] .. key_group_off[g + 1])
+    // Terms of the multiscalar check that share a point are merged before the bucket sort (their scalars add): pairs (a value
+    // commitment's sigma-proof term and its range-proof term, one per commitment and transfer) and runs (the terms on each
+    // account key: source and destination keys recur in every proof of an account's transactions), group g of the runs being
+    // key_terms[key_group_off[g] .. key_group_off[g + 1]) on the device
+    std::vector<u32> key_group_off;
     std::vector<u32> serial_txs;           // transactions whose transcript runs in the serial kernel
     std::vector<u32> tr_list;              // the others, sorted by template, each template padded to whole tiles of 64 (0xffffffff)
     std::vector<transcript_tile> tr_tiles; // one per 64 entries of tr_list
@@ -101,11 +102,7 @@ struct host_batch {
     xhe_verdict structural{1, XHE_OK, -1};
     // The large tables are written once per batch and their memory is worth keeping: a freed batch leaves it to the next one
     // (fresh pages cost a fault each, more than writing them).
-    void trade_storage(host_batch &o) {
-        txs.trade_storage(o.txs); cms.trade_storage(o.cms); xfers.trade_storage(o.xfers); decs.trade_storage(o.decs); early_decs.trade_storage(o.early_decs);
-        key_decs.trade_storage(o.key_decs); bulk_decs.trade_storage(o.bulk_decs); ops.trade_storage(o.ops); sigs.trade_storage(o.sigs); tx_err.trade_storage(o.tx_err);
-        apply_err.trade_storage(o.apply_err); segs.trade_storage(o.segs); merge_pairs.trade_storage(o.merge_pairs); key_terms.trade_storage(o.key_terms);
-    }
+    void trade_storage(host_batch &o) { ex_txs.trade_storage(o.ex_txs); ex_xfs.trade_storage(o.ex_xfs); ex_cms.trade_storage(o.ex_cms); }
 };
 
 // fn(lo, hi) over [0, count) on up to `threads` host threads (the calling thread takes the first range)
@@ -269,8 +266,9 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
 
     lap("prefix sums");
     // ---- pass C (sequential): everything the order of the transactions decides ----
-    std::vector<dev_dec> shared_decs;                  // positions blk[n] + index
-    std::vector<u32> shared_early, shared_key;
+    std::vector<dev_dec> &shared_decs = hb.shared_decs;    // positions blk[n] + index
+    std::vector<u32> &shared_early = hb.shared_early, &shared_key = hb.shared_key;
+    shared_decs.clear(); shared_early.clear(); shared_key.clear();
     auto new_shared = [&](u64 off, u32 early) -> u32 {
         const u32 pos = blk[n] + (u32)shared_decs.size();
         shared_decs.push_back({off});
@@ -278,7 +276,8 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         return pos;
     };
     std::vector<u32> acc_pos(lv.n_accounts, NONE), acc_keyslot(lv.n_accounts, NONE), used_slot(lv.n_balances, NONE);
-    std::vector<u32> slot_pos, ops_count;               // per used slot: position of its initial C (D = +1), operations so far
+    std::vector<u32> &slot_pos = hb.slot_pos; slot_pos.clear();
+    std::vector<u32> ops_count;                        // per used slot: operations so far (slot_pos: position of its initial C, D = +1)
     std::unordered_map<u64, u32> signer_pos;           // byte offset of a signer key -> position
     std::unordered_map<u32, u32> pos_keyslot;          // position of a signer / unknown-source key -> position in sig_keys
     struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
@@ -312,8 +311,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     std::vector<u32> cm_slot(n_cm, NONE), cm_local(n_cm, 0), xf_slot(n_xf, NONE), xf_local(n_xf, 0), xf_dest_pos(n_xf, NONE);
     std::vector<u8> cm_fresh(n_cm, 0), xf_fresh(n_xf, 0);
     std::vector<u32> key_cnt(lv.n_accounts, 0), src_keylocal(n), xf_keylocal(n_xf, NONE);      // terms on each account's key, and where a transaction's come in its run
-    struct ms_entry { u32 tx, k, key_pos, key_slot; u64 key_off; };
-    std::vector<ms_entry> ms_entries;                  // co-signatures to verify, in transaction order
+    std::vector<expand_ms> &ms_entries = hb.ex_mss; ms_entries.clear();       // co-signatures to verify, in transaction order
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_map;
     transcript_shape last_shape{255, 0, 0, 0, 0, 0}; u32 last_tmpl = TT_NONE;
     hb.lg_groups.assign(16, {});
@@ -361,7 +359,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                             const u64 koff = cfg.signer_off[idx];
                             auto sp = signer_pos.find(koff);
                             const u32 kp = sp != signer_pos.end() ? sp->second : (signer_pos[koff] = new_shared(koff, 2));
-                            ms_entries.push_back({(u32)i, k, kp, keyslot_of_pos(kp), koff});
+                            ms_entries.push_back({koff, (u32)i, k, kp, keyslot_of_pos(kp)});
                             sigs++;
                         }
                     }
@@ -407,26 +405,15 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     }
     lap("ordered walk");
     const u32 n_slots = (u32)slot_pos.size();
-    std::vector<u32> slot_base(n_slots + 1);
+    std::vector<u32> &slot_base = hb.slot_base; slot_base.resize(n_slots + 1);
     { u32 o = 0; for (u32 u = 0; u < n_slots; u++) { slot_base[u] = o; o += ops_count[u]; } slot_base[n_slots] = o; }
 
     // ---- sizes ----
-    const u32 n_decs = blk[n] + (u32)shared_decs.size();
-    hb.txs.resize(n); hb.tx_err.assign(n, ERRKEY_NONE); hb.apply_err.assign(n, ERRKEY_NONE);
-    hb.cms.resize(n_cm); hb.xfers.resize(n_xf); hb.sigs.resize(sig_base[n]); hb.segs.resize(seg_base[n]);
-    hb.decs.resize(n_decs);
-    std::copy(shared_decs.begin(), shared_decs.end(), hb.decs.begin() + blk[n]);
-    hb.early_decs.resize(early_base[n] + shared_early.size()); std::copy(shared_early.begin(), shared_early.end(), hb.early_decs.begin() + early_base[n]);
-    hb.key_decs.resize(key_base[n] + shared_key.size()); std::copy(shared_key.begin(), shared_key.end(), hb.key_decs.begin() + key_base[n]);
-    hb.bulk_decs.resize(bulk_base[n]);
-    hb.ops.resize(slot_base[n_slots]);
-    hb.slot_last_op.resize(n_slots);
-    for (u32 u = 0; u < n_slots; u++) {
-        dev_op init{}; init.slot = u; init.kind = 0; init.c_pt = hb.n_static + slot_pos[u]; init.d_pt = init.c_pt + 1; init.emit = NONE; init.first = 1;
-        hb.ops[slot_base[u]] = init;
-        hb.slot_last_op[u] = slot_base[u + 1] - 1;
-    }
-    hb.emit_base = hb.n_static + n_decs;
+    hb.n_cm = n_cm; hb.n_xf = n_xf; hb.n_sigs = sig_base[n]; hb.n_segs = seg_base[n]; hb.n_ops = slot_base[n_slots];
+    hb.blk_end = blk[n]; hb.early_end = early_base[n]; hb.key_end = key_base[n];
+    hb.n_decs = blk[n] + (u32)shared_decs.size();
+    hb.n_early = early_base[n] + (u32)shared_early.size(); hb.n_key = key_base[n] + (u32)shared_key.size(); hb.n_bulk = bulk_base[n];
+    hb.emit_base = hb.n_static + hb.n_decs;
     hb.n_emit = 2 * n_cm;
     hb.n_points = hb.emit_base + hb.n_emit;
     // challenges and range-proof terms follow in transaction order
@@ -447,137 +434,58 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         hb.key_group_off.clear();
         for (u64 a = 0; a < lv.n_accounts; a++) if (key_cnt[a] >= 2) { key_run[a] = o; hb.key_group_off.push_back(o); o += key_cnt[a]; }
         hb.key_group_off.push_back(o);
-        hb.key_terms.resize(o);
-        hb.merge_pairs.resize(2ull * (n_cm + n_xf));
+        hb.n_key_terms = o;
     }
     // co-signatures by transaction: ms_entries is in transaction order, so a transaction's entries follow its main signature
     std::vector<u32> ms_first(n + 1, 0);
     { for (auto &e : ms_entries) ms_first[e.tx + 1]++; for (u64 i = 0; i < n; i++) ms_first[i + 1] += ms_first[i]; }
+    hb.emit_slot.assign(n_cm, 0);
+    hb.ex_txs.resize(n); hb.ex_xfs.resize(n_xf); hb.ex_cms.resize(n_cm);
 
     lap("tables sized");
-    // ---- pass D (parallel): the descriptors ----
+    // ---- pass D (parallel): the records the device expands into descriptors ----
     ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
         for (u64 i = lo; i < hi; i++) {
             const tx_record &t = recs[i];
-            dev_tx &d = hb.txs[i];
-            memset(&d, 0, sizeof d);
-            const u64 rec = offsets[i];
-            const u32 T = (u32)t.transfer_off.size(), A = t.n_commitments, lg = t.lg();
-            d.rec = rec; d.pre_off = t.pre_off; d.pre_len = t.pre_len; d.payload_off = t.payload_off; d.rp_off = t.rp_off; d.cm_off = t.cm_off;
-            d.ms_off = t.ms_off; d.sig_off = t.sig_off;
-            d.n_transfers = (u16)T; d.n_commitments = t.n_commitments; d.n_multisig = t.n_multisig; d.n_items = t.n_items;
-            d.type = t.type; d.lg = (u8)lg; d.version = t.version; d.flags = t.flags; d.m = t.m(); d.fee = t.fee; d.nonce = t.nonce;
-            d.hash_idx = hash_idx[i];
-            d.xfer_first = xf_base[i]; d.cm_first = cm_base[i];
-            d.chal_off = chal_off[i]; d.rp_term_off = rp_term[i]; d.rp_row = rp_row[i];
-            d.tmpl_off = tmpl_of_tx[i]; d.seg_off = seg_base[i];
-            {
-                u32 *sg = hb.segs.data() + seg_base[i];
-                *sg++ = t.pre_off; *sg++ = t.rp_off;
-                for (u32 k = 0; k < A; k++) *sg++ = t.cm_off + 256 * k;
-                for (u32 k = 0; k < T; k++) { *sg++ = t.transfer_off[k]; *sg++ = t.transfer_off[k] + t.transfer_len[k] - 160; }
-            }
-            u32 key = step_err[i], akey = ERRKEY_NONE;
-            auto raise = [&](u32 k2) { if (k2 < key) key = k2; };
-            auto raise_state = [&](u32 k2) { raise(k2); if (k2 < akey) akey = k2; };
-            // the block of points
-            u32 pos = blk[i], ei = early_base[i], bi = bulk_base[i];
-            auto put = [&](u64 off, u32 early) {
-                hb.decs[pos] = {off};
-                if (early == 1) hb.early_decs[ei++] = pos; else if (early == 2) hb.key_decs[key_base[i]] = pos; else hb.bulk_decs[bi++] = pos;
-                return hb.n_static + pos++;
-            };
-            d.rp_pt = put(rec + t.rp_off, 0);
-            for (u32 k = 1; k < 4; k++) put(rec + t.rp_off + 32 * k, 0);
-            for (u32 k = 0; k < 2 * lg; k++) put(rec + t.rp_off + 224 + 32 * k, 0);
-            // source account, nonce (verify.rs:210-221)
+            const u32 T = (u32)t.transfer_off.size(), A = t.n_commitments;
             const u32 sa = src_acc[i];
-            if (sa == NONE) { raise_state(errkey(ST_NONCE, 0, 0, XHE_ERR_STATE)); d.src_pt = put(rec + t.pre_off + 1, 2); }
-            else {
-                if (lv.account_nonces[sa] != t.nonce) raise(errkey(ST_NONCE, 0, 1, XHE_ERR_INVALID_NONCE));
-                d.src_pt = hb.n_static + src_pos[i];
-            }
-            if (!record_commitment_assets_ok(t)) raise(errkey(ST_ASSETS, 0, 0, XHE_ERR_FORMAT));
-            // main signature over pre-image || multisig entries (verify.rs:253-256), then the co-signatures
-            {
-                u32 si = sig_base[i];
-                dev_sig s{}; s.tx = (u32)i; s.key_pt = d.src_pt; s.key_off = rec + t.pre_off + 1; s.msg_off = rec + t.pre_off; s.msg_len = t.pre_len + 65u * t.n_multisig;
-                s.hash_idx = NONE; s.sig_off = rec + t.sig_off; s.err_key = errkey(ST_SIGNATURE, 0, 0, XHE_ERR_SIGNATURE); s.key_err_key = 0;
-                s.key_slot = src_keyslot[i];
-                hb.sigs[si++] = s;
-                for (u32 e = ms_first[i]; e < ms_first[i + 1]; e++) {
-                    const ms_entry &me = ms_entries[e];
-                    dev_sig c{}; c.tx = (u32)i; c.key_pt = hb.n_static + me.key_pos; c.key_off = me.key_off; c.msg_off = 0; c.msg_len = 32; c.hash_idx = hash_idx[i];
-                    c.sig_off = rec + t.ms_off + 65ull * me.k + 1; c.err_key = errkey(ST_MULTISIG, me.k, 3, XHE_ERR_SIGNATURE);
-                    c.key_err_key = errkey(ST_MULTISIG, me.k, 2, XHE_ERR_DECOMPRESSION);
-                    c.key_slot = me.key_slot;
-                    hb.sigs[si++] = c;
-                }
-            }
-            // transfers' points: C, D_s, D_r, Y_0, Y_1, Y_2
-            const u32 xf_pt0 = hb.n_static + pos;
-            for (u32 k = 0; k < T; k++) {
-                const u64 o = rec + t.transfer_off[k], po = o + t.transfer_len[k] - 160;
-                put(o + 64, 1); put(o + 96, 1); put(o + 128, 1);
-                put(po, 0); put(po + 32, 0); put(po + 64, 0);
-            }
-            // commitments (verify.rs:296-341)
+            expand_tx e;
+            memset(&e, 0, sizeof e);
+            e.rec = offsets[i]; e.fee = t.fee; e.nonce = t.nonce;
+            e.pre_off = t.pre_off; e.pre_len = t.pre_len; e.payload_off = t.payload_off; e.rp_off = t.rp_off; e.cm_off = t.cm_off; e.ms_off = t.ms_off; e.sig_off = t.sig_off;
+            e.m = t.m();
+            e.hash_idx = hash_idx[i]; e.xfer_first = xf_base[i]; e.cm_first = cm_base[i]; e.chal_off = chal_off[i]; e.rp_term_off = rp_term[i]; e.rp_row = rp_row[i];
+            e.tmpl_off = tmpl_of_tx[i]; e.seg_off = seg_base[i]; e.step_err = step_err[i];
+            e.blk = blk[i]; e.early_base = early_base[i]; e.key_base = key_base[i]; e.bulk_base = bulk_base[i];
+            e.src_pos = src_pos[i]; e.sig_base = sig_base[i]; e.src_keyslot = src_keyslot[i];
+            e.ms_first = ms_first[i]; e.ms_count = ms_first[i + 1] - ms_first[i];
+            e.cm_term = cm_term[i]; e.xf_term = xf_term[i];
+            e.src_key_term = (sa != NONE && key_run[sa] != NONE) ? key_run[sa] + src_keylocal[i] : NONE;
+            e.n_transfers = (u16)T; e.n_commitments = t.n_commitments; e.n_multisig = t.n_multisig; e.n_items = t.n_items;
+            e.type = t.type; e.lg = (u8)t.lg(); e.version = t.version; e.flags = t.flags;
+            e.src_known = sa != NONE; e.nonce_ok = sa != NONE && lv.account_nonces[sa] == t.nonce; e.assets_ok = record_commitment_assets_ok(t);
+            hb.ex_txs[i] = e;
             for (u32 k = 0; k < A; k++) {
-                const u32 ci = cm_base[i] + k;
-                dev_cm c{}; c.tx = (u32)i; c.idx = k; c.off = rec + t.cm_off + 256ull * k;
-                c.pt = put(c.off + 32, 0); put(c.off + 64, 0); put(c.off + 96, 0); put(c.off + 128, 0);
-                c.term_off = cm_term[i] + 7 * k;
-                c.src_ct_pt = hb.emit_base + 2 * ci; c.slot_pt = 0; c.first_touch = 0;
-                // C_new is the point of the proof's term 5 and of the range proof's value commitment k; P_source that of term 0
-                hb.merge_pairs[2ull * (ci + xf_base[i])] = c.term_off + 5; hb.merge_pairs[2ull * (ci + xf_base[i]) + 1] = rp_term[i] + 4 + 2 * lg + k;
-                if (sa != NONE && key_run[sa] != NONE) hb.key_terms[key_run[sa] + src_keylocal[i] + k] = c.term_off;
-                const u32 u = cm_slot[ci];
-                if (u == NONE) raise_state(errkey(ST_COMMITMENT, k, 0, XHE_ERR_STATE));
-                else {
-                    c.slot_pt = hb.n_static + slot_pos[u]; c.first_touch = cm_fresh[ci];
-                    const u8 *asset = t.commitment(k);
-                    u32 o = slot_base[u] + cm_local[ci];
-                    // get_sender_output_ct (verify.rs:107-144): transfers of this asset, burn / contract amount, fee
-                    for (u32 x = 0; x < T; x++)
-                        if (xf_cm[xf_base[i] + x] == k) {
-                            dev_op op{}; op.slot = u; op.kind = 1; op.emit = NONE; op.first = 0;
-                            op.c_pt = xf_pt0 + 6 * x; op.d_pt = op.c_pt + 1;      // (C, D_sender)
-                            hb.ops[o++] = op;
-                        }
-                    const u64 amount = cm_amount[ci];
-                    if (amount) { dev_op op{}; op.slot = u; op.kind = 2; op.amount = amount; op.emit = NONE; hb.ops[o++] = op; }
-                    dev_op fin{}; fin.slot = u; fin.kind = 2; fin.amount = rec_is_zero32(asset) ? t.fee : 0; fin.emit = ci;
-                    hb.ops[o++] = fin;
-                }
-                hb.cms[ci] = c;
+                const u32 ci = cm_base[i] + k, u = cm_slot[ci];
+                expand_cm c;
+                memset(&c, 0, sizeof c);
+                c.amount = cm_amount[ci]; c.slot = u;
+                if (u != NONE) { c.slot_pos = slot_pos[u]; c.op_pos = slot_base[u] + cm_local[ci]; c.fresh = cm_fresh[ci]; hb.emit_slot[ci] = u; }
+                c.native = rec_is_zero32(t.commitment(k));
+                hb.ex_cms[ci] = c;
             }
-            // transfers (verify.rs:345-395)
             for (u32 k = 0; k < T; k++) {
-                const u32 xi = xf_base[i] + k;
-                dev_xfer x{}; x.tx = (u32)i; x.idx = k; x.off = rec + t.transfer_off[k]; x.proof_off = x.off + t.transfer_len[k] - 160;
-                x.pt = xf_pt0 + 6 * k;
-                x.term_off = xf_term[i] + 8 * k;
-                // C is the point of the proof's term 0 and of value commitment A + k; P_source that of term 5, P_dest of term 2
-                hb.merge_pairs[2ull * (cm_base[i] + A + xi)] = x.term_off; hb.merge_pairs[2ull * (cm_base[i] + A + xi) + 1] = rp_term[i] + 4 + 2 * lg + A + k;
-                if (sa != NONE && key_run[sa] != NONE) hb.key_terms[key_run[sa] + src_keylocal[i] + A + k] = x.term_off + 5;
-                if (xf_keylocal[xi] != NONE && key_run[xf_acc[xi]] != NONE) hb.key_terms[key_run[xf_acc[xi]] + xf_keylocal[xi]] = x.term_off + 2;
-                if (xf_acc[xi] == NONE) {
-                    x.dest_pt = put(x.off + 32, 0);
-                    x.state_err = 1;
-                    raise_state(errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE));
-                } else {
-                    x.dest_pt = hb.n_static + xf_dest_pos[xi];
-                    const u32 u = xf_slot[xi];
-                    if (u == NONE) { x.state_err = 1; raise_state(errkey(ST_TRANSFER, k, 1, XHE_ERR_STATE)); }
-                    else {
-                        x.slot_pt = hb.n_static + slot_pos[u]; x.first_touch = xf_fresh[xi];
-                        dev_op op{}; op.slot = u; op.kind = 0; op.c_pt = x.pt; op.d_pt = x.pt + 2; op.emit = NONE;
-                        hb.ops[slot_base[u] + xf_local[xi]] = op;
-                    }
-                }
-                hb.xfers[xi] = x;
+                const u32 xi = xf_base[i] + k, da = xf_acc[xi], u = xf_slot[xi];
+                expand_xf x;
+                memset(&x, 0, sizeof x);
+                x.off = t.transfer_off[k]; x.len = t.transfer_len[k];
+                x.has_account = da != NONE; x.dest_pos = xf_dest_pos[xi];
+                x.slot = u;
+                if (u != NONE) { x.slot_pos = slot_pos[u]; x.op_pos = slot_base[u] + xf_local[xi]; x.fresh = xf_fresh[xi]; }
+                x.key_term = (da != NONE && xf_keylocal[xi] != NONE && key_run[da] != NONE) ? key_run[da] + xf_keylocal[xi] : NONE;
+                x.cm = xf_cm[xi];
+                hb.ex_xfs[xi] = x;
             }
-            hb.tx_err[i] = key; hb.apply_err[i] = akey;
         }
     });
 

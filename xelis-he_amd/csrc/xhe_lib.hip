@@ -40,6 +40,7 @@ struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
     u64 n_balances = 0, n_accounts = 0;
     std::vector<u8> in_cts; std::vector<u64> in_nonces;
+    dev_buf ex_txs, ex_xfs, ex_cms, ex_mss, sh_decs, sh_early, sh_key, ex_slot_pos, ex_slot_base;     // inputs of the descriptor expansion
     dev_buf merge_pairs, key_terms, key_group_off, bytes, txs, cms, xfers, decs, early_decs, key_decs, bulk_decs, sig_keys, sig_tab, ops, sigs, tx_err0, apply_err0, slot_last_op, emit_slot, ms_hash_tx, group_txs, tmpl, segs, serial_txs, tr_list, tr_tiles, tr_stream, sig_state, sig_r;
     u64 rp_gemm_min_rows = ~0ull;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, rp_dig, rp_bins, rp_rho, tx_err, rp_err, ms_hash;
@@ -49,7 +50,7 @@ struct xhe_batch {
     hipEvent_t ev_uploaded = nullptr;   // fires on the copy stream when every table of the batch has arrived
     bool verified_ok = false;
     void release() {
-        for (dev_buf *b : {&merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
+        for (dev_buf *b : {&ex_txs, &ex_xfs, &ex_cms, &ex_mss, &sh_decs, &sh_early, &sh_key, &ex_slot_pos, &ex_slot_base, &merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &rp_dig, &rp_bins, &rp_rho, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
             b->release();
@@ -412,8 +413,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     if (!parsed) { (void)hipStreamSynchronize(st); return 0; }
     int32_t rc = ensure_tables(ctx, hb.nm_cap);
     if (rc) { xhe_batch_free(ctx, B); *batch_out = nullptr; return rc; }
-    std::vector<u32> emit_slot(hb.cms.size(), 0);
-    for (auto &op : hb.ops) if (op.emit != 0xffffffffu) emit_slot[op.emit] = op.slot;
+    const std::vector<u32> &emit_slot = hb.emit_slot;
     std::vector<u32> group_txs; B->group_off.assign(17, 0);
     for (u32 lg = 0; lg < 16; lg++) { B->group_off[lg] = (u32)group_txs.size(); group_txs.insert(group_txs.end(), hb.lg_groups[lg].begin(), hb.lg_groups[lg].end()); }
     B->group_off[16] = (u32)group_txs.size();
@@ -444,22 +444,29 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         part(in->multisig_signers, hb.signers_base, 32 * hb.n_signer_keys);
         part(zeros, hb.signers_base + 32 * hb.n_signer_keys, 64);
     }
-    UP(txs, hb.txs); UP(cms, hb.cms); UP(xfers, hb.xfers); UP(decs, hb.decs); UP(early_decs, hb.early_decs); UP(key_decs, hb.key_decs); UP(bulk_decs, hb.bulk_decs); UP(sig_keys, hb.sig_keys); UP(ops, hb.ops); UP(sigs, hb.sigs);
-    UP(tmpl, hb.tmpl); UP(segs, hb.segs); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
-    UP(merge_pairs, hb.merge_pairs); UP(key_terms, hb.key_terms); UP(key_group_off, hb.key_group_off);
-    UP(tx_err0, hb.tx_err); UP(apply_err0, hb.apply_err); UP(slot_last_op, hb.slot_last_op); UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
+    // what the device expands (launch_expand below) into descriptors that live in the workspace block
+    UP(ex_txs, hb.ex_txs); UP(ex_xfs, hb.ex_xfs); UP(ex_cms, hb.ex_cms); UP(ex_mss, hb.ex_mss); UP(sh_decs, hb.shared_decs); UP(sh_early, hb.shared_early); UP(sh_key, hb.shared_key);
+    UP(ex_slot_pos, hb.slot_pos); UP(ex_slot_base, hb.slot_base);
+    UP(sig_keys, hb.sig_keys);
+    UP(tmpl, hb.tmpl); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
+    UP(key_group_off, hb.key_group_off);
+    UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
 #undef UP
     u64 n_slots = hb.slot_of_used.size();
-    u64 n_ops = hb.ops.size();
+    u64 n_ops = hb.n_ops;
     u64 scan_threads = (n_ops + SCAN_K - 1) / SCAN_K, scan_blocks = (scan_threads + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (scan_blocks == 0) scan_blocks = 1;
-    u64 n_parts = hb.cms.size() + hb.xfers.size() + hb.n_txs;
+    u64 n_parts = (u64)hb.n_cm + hb.n_xf + hb.n_txs;
 #define RS(buf, bytes_) add(wss, ws_total, B->buf, nullptr, (size_t)(bytes_))
+    RS(txs, sizeof(dev_tx) * hb.n_txs); RS(cms, sizeof(dev_cm) * (u64)hb.n_cm); RS(xfers, sizeof(dev_xfer) * (u64)hb.n_xf); RS(decs, sizeof(dev_dec) * (u64)hb.n_decs);
+    RS(early_decs, 4ull * hb.n_early); RS(key_decs, 4ull * hb.n_key); RS(bulk_decs, 4ull * hb.n_bulk); RS(ops, sizeof(dev_op) * (u64)hb.n_ops); RS(sigs, sizeof(dev_sig) * (u64)hb.n_sigs);
+    RS(segs, 4ull * hb.n_segs); RS(merge_pairs, 8ull * ((u64)hb.n_cm + hb.n_xf)); RS(key_terms, 4ull * hb.n_key_terms); RS(tx_err0, 4ull * hb.n_txs); RS(apply_err0, 4ull * hb.n_txs);
+    RS(slot_last_op, 4ull * hb.slot_pos.size());
     RS(pts, 128ull * hb.n_points); RS(ok, hb.n_points); RS(chal, 32ull * hb.n_chal); RS(scalars, 32ull * hb.n_terms); RS(term_point, 4ull * hb.n_terms);
     RS(gh, 72ull * n_parts); RS(gh_sums, 72ull * 256); RS(rp_ctx, 36ull * RPC_SCALARS * hb.n_txs); RS(rp_acc, 72ull * hb.nm_cap);
     RS(tx_err, 4ull * hb.n_txs); RS(rp_err, 4ull * hb.n_txs); RS(ms_hash, 32ull * hb.ms_hash_tx.size());
     RS(thread_excl, 256ull * scan_blocks * SCAN_BLOCK); RS(block_tot, 256ull * scan_blocks); RS(slot_base, 256ull * (n_slots + 1)); RS(slot_final, 256ull * (n_slots + 1));
-    RS(emit_incl, 256ull * (hb.cms.size() + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.sigs.size()); RS(sig_r, 128ull * hb.sigs.size()); RS(sig_tab, 4ull * SIG_KEY_TABLE_WORDS * hb.sig_keys.size());
+    RS(emit_incl, 256ull * ((u64)hb.n_cm + 1)); RS(final_cts, 64ull * (n_slots + 1)); RS(verdict, 64); RS(seed, 32); RS(tr_stream, 8ull * hb.tr_plan.stream_words); RS(sig_state, 200ull * hb.n_sigs); RS(sig_r, 128ull * hb.n_sigs); RS(sig_tab, 4ull * SIG_KEY_TABLE_WORDS * hb.sig_keys.size());
     // partial column sums of the range-proof scalar matrix: one row per tile of transactions
     // (groups with many transactions take the matrix-core path instead: digit tables of one chunk, partial diagonal sums)
     {
@@ -510,6 +517,21 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         if (up_total > room) wait_for_copies = true;
     }
     lap("tables staged and enqueued");
+    {
+        // the descriptors, decode lists, ledger operations and signature descriptors are written on the device, behind the copies
+        expand_args ea;
+        ea.txs = B->ex_txs.as<expand_tx>(); ea.xfs = B->ex_xfs.as<expand_xf>(); ea.cms = B->ex_cms.as<expand_cm>(); ea.mss = B->ex_mss.as<expand_ms>(); ea.n_txs = (u32)hb.n_txs;
+        ea.n_static = hb.n_static; ea.emit_base = hb.emit_base;
+        ea.out_txs = B->txs.as<dev_tx>(); ea.out_cms = B->cms.as<dev_cm>(); ea.out_xfers = B->xfers.as<dev_xfer>(); ea.decs = B->decs.as<dev_dec>();
+        ea.early_decs = B->early_decs.as<u32>(); ea.key_decs = B->key_decs.as<u32>(); ea.bulk_decs = B->bulk_decs.as<u32>(); ea.ops = B->ops.as<dev_op>(); ea.sigs = B->sigs.as<dev_sig>();
+        ea.segs = B->segs.as<u32>(); ea.merge_pairs = B->merge_pairs.as<u32>(); ea.key_terms = B->key_terms.as<u32>(); ea.tx_err = B->tx_err0.as<u32>(); ea.apply_err = B->apply_err0.as<u32>();
+        ea.shared_decs = B->sh_decs.as<dev_dec>(); ea.shared_early = B->sh_early.as<u32>(); ea.shared_key = B->sh_key.as<u32>(); ea.slot_pos = B->ex_slot_pos.as<u32>(); ea.slot_base = B->ex_slot_base.as<u32>();
+        ea.n_shared = (u32)hb.shared_decs.size(); ea.n_shared_early = (u32)hb.shared_early.size(); ea.n_shared_key = (u32)hb.shared_key.size(); ea.n_slots = (u32)hb.slot_pos.size();
+        ea.blk_end = hb.blk_end; ea.early_end = hb.early_end; ea.key_end = hb.key_end;
+        ea.slot_last_op = B->slot_last_op.as<u32>();
+        launch_expand(st, ea);
+        HIPCHK(ctx, hipGetLastError());
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev_stage_free, st));
     HIPCHK(ctx, hipEventRecord(B->ev_uploaded, st));
     if (wait_for_copies) HIPCHK(ctx, hipStreamSynchronize(st));
@@ -539,7 +561,7 @@ int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
     hipStream_t st = ctx->stream;
     B->verified_ok = false;
     if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
-    const u32 n_txs = (u32)hb.n_txs, n_cm = (u32)hb.cms.size(), n_ops = (u32)hb.ops.size(), n_slots = (u32)hb.slot_of_used.size();
+    const u32 n_txs = (u32)hb.n_txs, n_cm = hb.n_cm, n_ops = hb.n_ops, n_slots = (u32)hb.slot_of_used.size();
     stage_timer &tm = ctx->timer;
     tm.begin();
     std::shared_lock<std::shared_mutex> tables_lock(ctx->tables_mu);
@@ -563,7 +585,7 @@ int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
     if (n_txs) {
         u32 *pts = B->pts.as<u32>(); u8 *ok = B->ok.as<u8>();
         HIPCHK(ctx, tm.mark("decode_first", st));
-        launch_decode_list(st, B->bytes.as<u8>(), B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
+        launch_decode_list(st, B->bytes.as<u8>(), B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
         HIPCHK(ctx, tm.mark("ledger_scan", st));
         launch_ledger_scan(st, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
                            B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
@@ -702,8 +724,8 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     hipStream_t st = ctx->stream;
     B->verified_ok = false;
     if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
-    const u32 n_txs = (u32)hb.n_txs, n_cm = (u32)hb.cms.size(), n_xf = (u32)hb.xfers.size(), n_dec = (u32)hb.decs.size();
-    const u32 n_ops = (u32)hb.ops.size(), n_slots = (u32)hb.slot_of_used.size(), n_sigs = (u32)hb.sigs.size();
+    const u32 n_txs = (u32)hb.n_txs, n_cm = hb.n_cm, n_xf = hb.n_xf, n_dec = hb.n_decs;
+    const u32 n_ops = hb.n_ops, n_slots = (u32)hb.slot_of_used.size(), n_sigs = hb.n_sigs;
     const u32 n_parts = n_cm + n_xf + n_txs;
     stage_timer &tm = ctx->timer;
     tm.begin();
@@ -770,7 +792,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     hipStream_t ssig = one_stream ? st : (own_sig_stream ? ctx->side[2] : s1);
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
     HIPCHK(ctx, tm.open("decode_first", s0));
-    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), (u32)hb.early_decs.size(), hb.n_static, pts, ok);
+    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
     HIPCHK(ctx, tm.close("decode_first", s0));
     auto enqueue_scan = [&]() -> int32_t {
         HIPCHK(ctx, tm.open("ledger_scan", s0));
@@ -783,10 +805,10 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
     if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(ssig, ctx->ev_setup, 0));
     HIPCHK(ctx, tm.open("signatures", ssig));
-    launch_decode_list(ssig, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), (u32)hb.key_decs.size(), hb.n_static, pts, ok);
+    launch_decode_list(ssig, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), hb.n_key, hb.n_static, pts, ok);
     if (own_sig_stream) HIPCHK(ctx, hipEventRecord(ctx->ev_keys, ssig));
     HIPCHK(ctx, tm.open("decode_rest", s1));
-    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->bulk_decs.as<u32>(), (u32)hb.bulk_decs.size(), hb.n_static, pts, ok, true);
+    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->bulk_decs.as<u32>(), hb.n_bulk, hb.n_static, pts, ok, true);
     HIPCHK(ctx, tm.close("decode_rest", s1));
     if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_keys, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s1));             // every point that is not the ledger scan's
@@ -811,7 +833,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         launch_proof_scalars(st, pa);
         // terms on one point become one term: a value commitment's sigma and range-proof terms, every term on an account's key
         static const bool merge_terms = !(getenv("XHE_MERGE_TERMS") && getenv("XHE_MERGE_TERMS")[0] == '0');
-        if (merge_terms) launch_merge_terms(st, B->merge_pairs.as<u32>(), (u32)(hb.merge_pairs.size() / 2), B->key_group_off.as<u32>(), (u32)hb.key_group_off.size() - 1, B->key_terms.as<u32>(), scalars);
+        if (merge_terms) launch_merge_terms(st, B->merge_pairs.as<u32>(), hb.n_cm + hb.n_xf, B->key_group_off.as<u32>(), (u32)hb.key_group_off.size() - 1, B->key_terms.as<u32>(), scalars);
     }
     // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
     // parts).  With fixed-base tables their whole contribution is evaluated on side 0 while the main stream

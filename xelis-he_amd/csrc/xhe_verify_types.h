@@ -110,4 +110,49 @@ struct dev_sig {
     u32 key_slot;            // position of the key among the batch's distinct signing keys (its table of multiples)
 };
 
+
+// ---- descriptor expansion --------------------------------------------------------------------------------
+// The host's ordered walk over a batch decides few numbers per transaction, transfer and commitment (where its points, terms,
+// operations and signatures go); the descriptors above and the lists that follow from them (one entry per point, term or
+// operation) are written on the device by k_expand_descriptors from these records.
+struct expand_tx {
+    u64 rec, fee, nonce;
+    u32 pre_off, pre_len, payload_off, rp_off, cm_off, ms_off, sig_off, m;
+    u32 hash_idx, xfer_first, cm_first, chal_off, rp_term_off, rp_row, tmpl_off, seg_off;
+    u32 step_err;            // precedence key of what the walk itself found (multisig structure, MultiSig payload), or none
+    u32 blk, early_base, key_base, bulk_base;      // first position of the transaction's block in decs[] and in the three decode lists
+    u32 src_pos;             // position in decs[] of the source key
+    u32 sig_base, src_keyslot;
+    u32 ms_first, ms_count;  // its co-signatures in expand_ms[]
+    u32 cm_term, xf_term;    // first sigma-proof term of its commitments / transfers
+    u32 src_key_term;        // where its terms on the source key go in key_terms[] (0xffffffff: that key has a single term or is unknown)
+    u16 n_transfers, n_commitments, n_multisig, n_items;
+    u8 type, lg, version, flags;
+    u8 src_known, nonce_ok, assets_ok, pad;
+};
+struct expand_xf {
+    u32 off, len;            // the transfer inside its record
+    u32 dest_pos;            // position in decs[] of the destination key (used when has_account)
+    u32 slot, slot_pos, op_pos;      // receiver slot (0xffffffff: the ledger has none), position of its initial ciphertext, of this transfer's operation
+    u32 key_term;            // where its term on the destination key goes in key_terms[], or 0xffffffff
+    u16 cm;                  // the source commitment with the transfer's asset, 0xffff: none
+    u8 fresh, has_account;
+};
+struct expand_cm {
+    u64 amount;              // plain amount leaving the slot besides the fee (burn, contract deposit)
+    u32 slot, slot_pos, op_pos;      // sender slot (0xffffffff: none), its initial ciphertext, first of this commitment's operations
+    u8 fresh, native, pad[2];
+};
+struct expand_ms { u64 key_off; u32 tx, k, key_pos, key_slot; };
+struct expand_args {
+    const expand_tx *txs; const expand_xf *xfs; const expand_cm *cms; const expand_ms *mss; u32 n_txs;
+    u32 n_static, emit_base;
+    dev_tx *out_txs; dev_cm *out_cms; dev_xfer *out_xfers; dev_dec *decs; u32 *early_decs, *key_decs, *bulk_decs; dev_op *ops; dev_sig *sigs;
+    u32 *segs, *merge_pairs, *key_terms, *tx_err, *apply_err;
+    // the points shared between transactions and the slots' initial operations
+    const dev_dec *shared_decs; const u32 *shared_early, *shared_key, *slot_pos, *slot_base;
+    u32 n_shared, n_shared_early, n_shared_key, n_slots, blk_end, early_end, key_end;
+    u32 *slot_last_op;
+};
+
 }  // namespace xhe
