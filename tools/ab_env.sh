@@ -9,7 +9,8 @@ for rep in 1 2; do
     python - "$env_arg" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_env.json"))
-print(sys.argv[1], "rep", sys.argv[2], "ms_per_step", d["ms_per_step"], d["stages_ms"], "sig", d["stage_detail_ms"].get("signatures"), flush=True)
+sd = d["stage_detail_ms"]
+print(sys.argv[1], "rep", sys.argv[2], "ms_per_step", d["ms_per_step"], d["stages_ms"], "sig", sd.get("signatures"), "sort", [sd.get(k) for k in ("msm_histogram", "msm_scan", "msm_scatter", "msm_wait_points", "msm_merge", "msm_reduce")], flush=True)
 PY
   done
 done
