@@ -89,6 +89,23 @@ def test_full_batch_chain_gap(engine, batch):
 
 
 @pytest.mark.timeout(600)
+def test_full_batch_with_term_index_entries(engine, batch, monkeypatch):
+    """The bucket sort normally names point records in its entries; batches of 2^24 points and more keep term indices and the
+    accumulation looks the point up.  That form, forced here, gives the same verdicts and the same ledger."""
+    v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.setenv("XHE_MSM_TERM_ENTRIES", "1")
+    v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    assert (v0.accept, v1.accept) == (1, 1)
+    assert cts0 == cts1
+    rec = bytearray(batch.records)
+    rec[batch.offsets[4000] + 200] ^= 1               # inside transaction 4000's proofs
+    v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.delenv("XHE_MSM_TERM_ENTRIES")
+    v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
+
+
+@pytest.mark.timeout(600)
 def test_msm_linear_at_batch_term_count(engine):
     n = 350258                                        # terms of the 10 000-transaction check
     r = random.Random(350258)

@@ -674,7 +674,8 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     // With a term -> point map, the sort's entries name the point record directly when the index fits the entry (31 bits, 24 in
     // the two-pass format): the scatter reads the map in term order (coalesced), and the accumulate stage goes from entry to
     // record without a random 4-byte gather per entry in between.
-    const bool direct = d_term_point && n_points < (p.fine_bits ? (1ull << 24) - 1 : (1ull << 31) - 1);
+    // (XHE_MSM_TERM_ENTRIES=1 keeps term indices in the entries, the form batches of 2^24 points and more take: for tests)
+    const bool direct = d_term_point && n_points < (p.fine_bits ? (1ull << 24) - 1 : (1ull << 31) - 1) && !getenv("XHE_MSM_TERM_ENTRIES");
     const u32 *entry_point = direct ? d_term_point : nullptr;
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
     hipError_t e;
