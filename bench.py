@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (only with --backend gloo)")
     ap.add_argument("--split-one-batch", action="store_true",
                     help="with --gpus N: rank 0 generates ONE batch of N x --txs transactions, cuts it along its account groups (xhe_partition_batch) and hands "
-                         "every rank its shard; a step verifies the shards and MIN-reduces the 8-byte verdict key (BASELINE's one-batch-over-8-GPUs shape); "
+                         "every rank its shard; a step verifies the shards and MIN-reduces the 8-byte verdict key (the one-batch-over-eight-GPUs shape of the benchmark configurations); "
                          "the default is one independent batch per rank")
     return ap.parse_args()
 
@@ -333,7 +333,7 @@ def main():
                             "sample": "first %d transactions of the batch, one ledger clone per thread, %d threads (benches/tx.rs:307-325 style)" % (n_s, cores),
                             "single_thread_ms_per_tx": round(one / min(n_s, 256) * 1e3, 4), "reference_published_ms_per_tx_1_transfer": 0.40}
 
-    # after the timed region, rank 0 at N = 1: the drop-in call from host buffers, and BASELINE's 10 000 x 1-transfer configuration
+    # after the timed region, rank 0 at N = 1: the drop-in call from host buffers, and the 10 000 x 1-transfer configuration
     end_to_end, secondary = None, None
     if rank == 0 and args.gpus == 1:
         engine.set_stage_timing(0)

@@ -1,4 +1,4 @@
-"""The HIP path on BASELINE's largest single-GPU configuration (100 000 transactions, 8 transfers each, aggregated range
+"""The HIP path on the benchmark's largest single-GPU configuration (100 000 transactions, 8 transfers each, aggregated range
 proofs over 16 value commitments; 10.4 M multiscalar terms, window width 15, two-pass bucket sort), checked through
 properties that need no CPU verifier at that size, plus oracle parity on the same shape at sizes the oracle finishes in
 seconds: 14 000 transactions (1.46 M terms: the two-pass bucket sort with 14-bit windows) and a 1.6 M-term multiscalar
