@@ -12,6 +12,7 @@ from golden_io import FlatCase, primitives, tx_cases
 from helpers import buf
 from test_gpu_verify import ASSET55, _resigned, check_same
 from xelis_he_amd import codes
+from xelis_he_amd._capi import XheError
 from xelis_he_amd.api import NATIVE, Account, Ledger, Transaction, TransactionBuilder, TransactionUnsigned, TransferBuilder, Verdict
 
 pytestmark = pytest.mark.gpu
@@ -83,6 +84,46 @@ def test_error_variants_inside_a_batch(engine, oracle):
         txs[pos] = _resigned(unsigned[pos], alice.keypair, edits, "gap-in-%d" % pos)
         _, got = check_same(engine, oracle, txs, ledger, expect_accept=False, expect_code=code)
         assert got[2] == pos
+
+
+def test_random_lying_provers(engine, oracle):
+    """Differential run over seeded random lying provers: a chain of two-transfer transactions in which one transaction has one
+    or two bytes of its transfers, proofs, range proof or source commitment changed BEFORE it is signed, so the signature
+    holds and the error comes from the proof stages (identity / undecodable points, sigma proofs, the merged check and its
+    GenericProof / RangeProof split, non-canonical scalars).  Verdict, variant and index equal the oracle's every time."""
+    import random
+    alice = Account([(NATIVE, 1000)], "liar-a")
+    bob, carol = Account([(NATIVE, 0)], "liar-b"), Account([(NATIVE, 0)], "liar-c")
+    ledger = Ledger([alice, bob, carol])
+    prover, unsigned, bal = ledger.clone(), [], 1000
+    for k in range(5):
+        u = TransactionBuilder(1, alice.pubkey, ("transfers", [TransferBuilder(bob.pubkey, 1), TransferBuilder(carol.pubkey, 2)]), 3, 0).build_unsigned(
+            {NATIVE: bal}, alice.keypair, "liar-c%d" % k, prover.get_account(alice.pubkey))
+        u.sign(alice.keypair, "liar-cs%d" % k).apply_without_verify(prover)
+        bal -= 6
+        unsigned.append(u)
+    good = [u.sign(alice.keypair, "liar-g%d" % k) for k, u in enumerate(unsigned)]
+    check_same(engine, oracle, good, ledger, expect_accept=True)
+    body0 = 16 + 8 + 49                      # header, two extra-data lengths, version/source/fee/nonce: the transfers start here
+    r = random.Random(777)
+    seen = {}
+    for case in range(250):
+        pos = r.randrange(len(unsigned))
+        n = len(unsigned[pos].record)
+        edits = []
+        for _ in range(r.choice((1, 1, 2))):
+            off = r.randrange(body0, n)
+            edits.append((off, bytes([unsigned[pos].record[off] ^ (1 << r.randrange(8))])))
+        txs = list(good)
+        try:
+            txs[pos] = _resigned(unsigned[pos], alice.keypair, edits, "liar-%d" % case)
+        except XheError:                     # the builder refuses to sign a record that does not parse (a scalar made non-canonical)
+            seen["unsignable"] = seen.get("unsignable", 0) + 1
+            continue
+        _, got = check_same(engine, oracle, txs, ledger)
+        seen[got[1]] = seen.get(got[1], 0) + 1
+    print("verdict codes reached:", seen)
+    assert len([k for k in seen if k != "unsignable"]) >= 4, seen
 
 
 def test_multisig_index_out_of_range_is_skipped(engine, oracle):

@@ -328,6 +328,33 @@ def test_mixed_synthetic_batch(engine, oracle):
         assert g == r and g[0] == 0 and g[2] == tx, (tx, g, r)
 
 
+def test_random_corruptions_of_a_mixed_batch(engine, oracle):
+    """Differential run over seeded random corruptions of the mixed batch (one to three bytes changed anywhere in one to two
+    records: headers, keys, amounts, nonces, proof points and scalars, multisig entries, signatures): the verdict, the error
+    variant and the index of the failing transaction equal the oracle's for every one of them."""
+    import random
+    sb = SyntheticBatch(48, seed=b"mixed-fuzz", mixed=True)
+    offs = list(sb.offsets)
+    r = random.Random(20261114)
+    seen = {}
+    for case in range(600):
+        bad = bytearray(sb.records)
+        for _ in range(r.choice((1, 1, 1, 2))):
+            tx = r.randrange(sb.n_txs)
+            lo, hi = offs[tx], offs[tx + 1]
+            for _ in range(r.choice((1, 1, 2, 3))):
+                pos = r.randrange(lo, hi) if r.random() < 0.8 else r.randrange(lo, min(hi, lo + 80))     # some near the header and the source key
+                bad[pos] ^= 1 << r.randrange(8)
+        g, g_cts, g_ms = _raw_verify(engine.lib, engine, engine.ctx, sb, bytes(bad))
+        ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb, bytes(bad))
+        assert g == ref, (case, g, ref)
+        if g[0] == 1:
+            assert g_cts == ref_cts and g_ms == ref_ms, case
+        seen[g[1]] = seen.get(g[1], 0) + 1
+    print("verdict codes reached:", dict(sorted(seen.items())))
+    assert len(seen) >= 5, seen              # the corruptions reach several error variants, not one
+
+
 def test_apply_without_verify_batch(engine, oracle):
     """xhe_batch_apply (the ledger scan alone) against the host's apply_without_verify run transaction by transaction,
     and against the ledger an accepting verify_batch leaves; unknown receivers and broken ciphertexts are reported."""
