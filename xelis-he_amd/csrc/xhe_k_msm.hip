@@ -436,6 +436,12 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict
     };
     u32 e_cur, raw_cur[24]; bool valid_cur;
     fetch(start, e_cur, valid_cur, raw_cur);
+    // The first record must have ARRIVED before the loop is entered: inside the loop the current record's registers are then
+    // written by register moves only, and the compiler need not drain the loads in flight (the fresh prefetch) before every
+    // addition -- with the first record's loads still pending at the loop's head it did, because the bucket-border path in
+    // between may issue any number of loads of its own.
+#pragma unroll
+    for (int j = 0; j < 24; j++) asm volatile("" : "+v"(raw_cur[j]));
     for (u32 k = start; k < stop; k++) {
         u32 e_next = 0, raw_next[24]; bool valid_next = false;
         if (k + 1 < stop) fetch(k + 1, e_next, valid_next, raw_next);
