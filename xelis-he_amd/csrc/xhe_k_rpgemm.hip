@@ -89,7 +89,6 @@ __global__ void __launch_bounds__(64) k_rp_digits(const u32 *__restrict__ group_
 
 // Workgroup: an 8 x 8 tile of (hi, lo) pairs (wavefront: 4 x 4), one kind, one slice of the chunk's k-blocks.  Output: per pair
 // the 63 anti-diagonal sums of its 32 x 32 digit-product tile, bins[kind][slice][hi][lo][64].
-static constexpr u32 RPG_MAX_KB_PER_SLICE = 64;     // 2048 transactions: |diagonal sum| <= 32 * 2048 * 2^14 < 2^31
 __global__ void __launch_bounds__(256) k_rp_gemm(const u8 *__restrict__ dig, u32 lg, u32 kb_stride, u32 kb_per_slice, int *__restrict__ bins) {
     __shared__ int diag[4][16][64];
     const u32 l = (lg + 1) / 2, h = lg - l, n_lo = 1u << l, n_hi = 1u << h, per = n_lo + n_hi;

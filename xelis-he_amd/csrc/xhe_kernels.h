@@ -114,6 +114,7 @@ void launch_rp_colsum(hipStream_t st, const u32 *mat, u32 n_rows, u32 lg, u32 nm
 // to fill it.  A group is processed in chunks of chunk_rows transactions: dig holds one chunk's digit tables, bins the partial
 // diagonal sums of its slices, rho_part RP_GEMM_RHO_PARTS scalars.
 static constexpr u32 RP_GEMM_RHO_PARTS = 64;
+static constexpr u32 RP_GEMM_MAX_KB_PER_SLICE = 64;     // 2 048 transactions per slice: |anti-diagonal sum| <= 32 * 2048 * 2^14 < 2^31
 struct rp_gemm_plan { u32 l, h, n_lo, n_hi, per, chunk_rows, kb_per_slice, max_slices; u64 dig_bytes, bins_bytes; };
 static inline rp_gemm_plan rp_gemm_plan_for(u64 n_rows, u32 lg) {
     rp_gemm_plan p;
@@ -123,8 +124,8 @@ static inline rp_gemm_plan rp_gemm_plan_for(u64 n_rows, u32 lg) {
     chunk = std::min<u64>(chunk, (n_rows + 63) & ~63ull);
     p.chunk_rows = (u32)std::max<u64>(chunk, 64);
     const u32 kb = p.chunk_rows / 32, tiles = (p.n_hi / 8) * (p.n_lo / 8);
-    // enough workgroups to fill the device, and at most 64 k-blocks per slice (the diagonal sums are 32-bit)
-    u32 slices = std::max<u32>((kb + 63) / 64, std::min<u32>(kb, (1024 + 3 * tiles - 1) / (3 * tiles)));
+    // enough workgroups to fill the device, and a bounded slice (the diagonal sums are 32-bit)
+    u32 slices = std::max<u32>((kb + RP_GEMM_MAX_KB_PER_SLICE - 1) / RP_GEMM_MAX_KB_PER_SLICE, std::min<u32>(kb, (1024 + 3 * tiles - 1) / (3 * tiles)));
     p.kb_per_slice = (kb + slices - 1) / slices;
     p.max_slices = (kb + p.kb_per_slice - 1) / p.kb_per_slice;
     p.dig_bytes = bytes_per_tx * p.chunk_rows;
