@@ -106,6 +106,23 @@ def test_full_batch_with_term_index_entries(engine, batch, monkeypatch):
 
 
 @pytest.mark.timeout(600)
+def test_full_batch_with_one_pass_sort(engine, batch, monkeypatch):
+    """The one-pass bucket sort at 14-bit windows (the form inputs beyond 2^24 terms take, all 2^13 counters of a window in
+    LDS), forced on the 350 000-term batch: same verdicts, same ledger."""
+    v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.setenv("XHE_MSM_ONEPASS", "1")
+    v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    assert (v0.accept, v1.accept) == (1, 1)
+    assert cts0 == cts1
+    rec = bytearray(batch.records)
+    rec[batch.offsets[123] + 300] ^= 2
+    v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.delenv("XHE_MSM_ONEPASS")
+    v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
+
+
+@pytest.mark.timeout(600)
 def test_msm_linear_at_batch_term_count(engine):
     n = 350258                                        # terms of the 10 000-transaction check
     r = random.Random(350258)
