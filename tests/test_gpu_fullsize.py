@@ -123,6 +123,21 @@ def test_full_batch_with_one_pass_sort(engine, batch, monkeypatch):
 
 
 @pytest.mark.timeout(600)
+def test_full_batch_without_term_merging(engine, batch, monkeypatch):
+    """Terms that share a point are merged before the bucket sort; unmerged (XHE_MERGE_TERMS=0) the check is the same sum."""
+    monkeypatch.setenv("XHE_MERGE_TERMS", "0")
+    v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    rec = bytearray(batch.records)
+    rec[batch.offsets[9000] + 500] ^= 8
+    v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.delenv("XHE_MERGE_TERMS")
+    v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    assert (v0.accept, v1.accept) == (1, 1) and cts0 == cts1
+    assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
+
+
+@pytest.mark.timeout(600)
 def test_msm_linear_at_batch_term_count(engine):
     n = 350258                                        # terms of the 10 000-transaction check
     r = random.Random(350258)

@@ -832,7 +832,8 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
         launch_proof_scalars(st, pa);
         // terms on one point become one term: a value commitment's sigma and range-proof terms, every term on an account's key
-        static const bool merge_terms = !(getenv("XHE_MERGE_TERMS") && getenv("XHE_MERGE_TERMS")[0] == '0');
+        const char *merge_env = getenv("XHE_MERGE_TERMS");
+        const bool merge_terms = !(merge_env && merge_env[0] == '0');
         if (merge_terms) launch_merge_terms(st, B->merge_pairs.as<u32>(), hb.n_cm + hb.n_xf, B->key_group_off.as<u32>(), (u32)hb.key_group_off.size() - 1, B->key_terms.as<u32>(), scalars);
     }
     // The scalars of the static generators (column sums over all range proofs, sums of the per-proof B and H
