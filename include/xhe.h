@@ -133,7 +133,10 @@ typedef struct xhe_verdict {
  * order.  Two deliberate differences from the reference: on reject `out` is not written
  * (the reference leaves its state half-updated), and an unknown account or asset is XHE_ERR_STATE (the
  * reference's mock ledger panics).  rng_seed seeds the batch-factor generator (the reference draws
- * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it. */
+ * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it.
+ * A batch whose records reach 128 MiB is cut into consecutive parts inside the call (the host's parsing of part k + 1 runs
+ * beside the device's verification of part k, every part against the ledger the part before it left); verdict, index and
+ * ledger are those of the batch in one piece.  XHE_SPLIT_PARTS in the environment sets the number of parts (1: never cut). */
 int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
                          const xhe_ledger_view *in, const xhe_ledger_out *out, xhe_verdict *verdict,
                          const uint8_t rng_seed[32]);

@@ -123,6 +123,31 @@ def test_full_batch_with_one_pass_sort(engine, batch, monkeypatch):
 
 
 @pytest.mark.timeout(600)
+def test_full_batch_cut_into_parts(engine, batch, monkeypatch):
+    """Batches from 128 MiB of records on are verified in consecutive parts, each against the ledger the part before it left
+    (1 024 senders here, every one with transactions in every part).  Forced on this batch with 4 and 7 parts: the ledger of
+    the batch in one piece, a bad signature at its index in the whole batch, a broken chain as GenericProof."""
+    monkeypatch.setenv("XHE_SPLIT_PARTS", "1")
+    v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    assert v0.accept == 1
+    rec = bytearray(batch.records)
+    rec[batch.offsets[7777 + 1] - 40] ^= 0x10
+    offs = [batch.offsets[i] for i in range(batch.n_txs + 1)]
+    drop = 5
+    cut = offs[drop + 1] - offs[drop]
+    gap_records = batch.records[:offs[drop]] + batch.records[offs[drop + 1]:]
+    gap_offsets = (ctypes.c_uint64 * batch.n_txs)(*(offs[:drop + 1] + [o - cut for o in offs[drop + 2:]]))
+    for parts in ("4", "7"):
+        monkeypatch.setenv("XHE_SPLIT_PARTS", parts)
+        v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+        assert v1.accept == 1 and cts1 == cts0, parts
+        v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+        assert (v2.accept, v2.err_code, v2.first_bad_tx) == (0, codes.ERR_SIGNATURE, 7777), parts
+        v3, _ = _verify(engine, gap_records, gap_offsets, batch.n_txs - 1, batch.view)
+        assert (v3.accept, v3.err_code, v3.first_bad_tx) == (0, codes.ERR_GENERIC_PROOF, -1), parts
+
+
+@pytest.mark.timeout(600)
 def test_full_batch_without_term_merging(engine, batch, monkeypatch):
     """Terms that share a point are merged before the bucket sort; unmerged (XHE_MERGE_TERMS=0) the check is the same sum."""
     monkeypatch.setenv("XHE_MERGE_TERMS", "0")

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end time of xhe_verify_batch from host buffers (parse + upload + verify + ledger read-back) on one synthetic
 batch, repeated; XHE_UPLOAD_TIMES=1 in the environment prints the upload's phases.
-usage: tools/exp_e2e.py <txs> <transfers> [repeats]"""
+usage: tools/exp_e2e.py <txs> <transfers> [repeats] [parts,parts,...]
+The last argument repeats the measurement with XHE_SPLIT_PARTS set to each value (1 = the batch in one piece; default: the
+library's own choice)."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +15,13 @@ lib = _lib()
 eng = xelis_he_amd.Engine(0)
 batch = SyntheticBatch(n, t, min(1024, n), seed=b"e2e", threads=16, engine=eng)
 v = Verdict()
-for i in range(reps):
-    t0 = time.perf_counter()
-    rc = lib.xhe_verify_batch(ctypes.c_void_p(eng.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view, None, ctypes.byref(v), bytes([i + 1]) * 32)
-    dt = time.perf_counter() - t0
-    assert rc == 0 and v.accept == 1, (rc, v.accept, v.code)
-    print("E2E %d tx: %.3f ms  (%.0f tx/s)" % (n, dt * 1e3, n / dt), flush=True)
+settings = sys.argv[4].split(",") if len(sys.argv) > 4 else [None]
+for parts in settings:
+    if parts is not None:
+        os.environ["XHE_SPLIT_PARTS"] = parts
+    for i in range(reps):
+        t0 = time.perf_counter()
+        rc = lib.xhe_verify_batch(ctypes.c_void_p(eng.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view, None, ctypes.byref(v), bytes([i + 1]) * 32)
+        dt = time.perf_counter() - t0
+        assert rc == 0 and v.accept == 1, (rc, v.accept, v.code)
+        print("E2E %d tx, parts %s: %.3f ms  (%.0f tx/s)" % (n, parts or "auto", dt * 1e3, n / dt), flush=True)

@@ -83,6 +83,7 @@ struct host_batch {
     std::vector<u32> ms_hash_tx;           // transactions whose pre-image BLAKE3 digest is needed
     std::vector<std::vector<u32>> lg_groups;   // transactions by lg (index = lg)
     std::vector<int64_t> multisig_set_by;  // per account
+    bool multisig_updated = false;         // a transaction of the batch changed an account's multisig configuration
     std::vector<u32> tmpl;                 // transcript templates of the batch's shapes
     // Terms of the multiscalar check that share a point are merged before the bucket sort (their scalars add): pairs (a value
     // commitment's sigma-proof term and its range-proof term, one per commitment and transfer) and runs (the terms on each
@@ -397,7 +398,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                         for (u32 k = 0; k < t.n_items; k++) c.signer_off.push_back(rec + t.payload_off + 1 + 32ull * k);
                         cfg_of[sa] = (int32_t)cfgs.size(); cfgs.push_back(c);
                     }
-                    hb.multisig_set_by[sa] = (int64_t)i;
+                    hb.multisig_set_by[sa] = (int64_t)i; hb.multisig_updated = true;
                 }
             }
         }
