@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
 // record index in niels[]; n_points bounds the gather.  (When the sort already wrote record indices, msm_launch passes no
 // map and the record count as n.)  chunk_sums[2t] = partial sum of the bucket that
 // began before the chunk, chunk_sums[2t+1] = partial sum of the bucket that continues after it.
-__global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
+__global__ void __launch_bounds__(256, 2) k_msm_accumulate_regs(const u32 *__restrict__ niels, u64 n, const u32 *__restrict__ term_point, u64 n_points,
                                                            const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets, u32 M,
                                                            u32 *__restrict__ bucket_sums, u32 *__restrict__ chunk_sums) {
     wave_priority_high();
@@ -457,6 +457,91 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate(const u32 *__restrict
         e_cur = e_next; valid_cur = valid_next;
 #pragma unroll
         for (int j = 0; j < 24; j++) raw_cur[j] = raw_next[j];
+    }
+    u32 *dst;
+    if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
+    else if (bend <= stop) dst = bucket_sums + 32ull * b;            // the bucket is complete inside the chunk
+    else dst = chunk_sums + 64ull * t + 32;
+    ge_store(dst, acc);
+}
+
+// The accumulation with the prefetched record held in LDS instead of in registers (k_msm_accumulate_regs above is the register
+// form, kept for entries that name terms and as XHE_MSM_ACC_STAGED=0).  A lane's next record is requested with six LDS-DMA loads
+// (global_load_lds_dwordx4: no register destination; one instruction writes 64 lanes x 16 bytes contiguously, so piece j of
+// every lane's record lies at stage[wave][j][lane]) as soon as the current record has been read out of LDS, and arrives while
+// the addition runs.  Two waits guard the one buffer: vmcnt(0) before the record is read (it has arrived), lgkmcnt(0) before
+// the next request (every read of it has returned).  Without the 24 registers of a record in flight the kernel fits 128
+// registers, four wavefronts per SIMD instead of three (5.62 -> 5.51 ms on the 100 000 x 8 batch: the stage is bound by issue
+// slots, not by latency).  Entries name point records (no term -> point map in this form).
+template <int A, int B>
+__device__ __forceinline__ fe_t<(A > B ? A : B)> fe_pick(const fe_t<A> &a, const fe_t<B> &b, bool flag) {
+    fe_t<(A > B ? A : B)> r; const u32 m = flag ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] ^ (m & (a.v[i] ^ b.v[i]));
+    return r;
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_msm_accumulate(const u32 *__restrict__ niels, u64 n_points, const u32 *__restrict__ offsets, const u32 *__restrict__ sorted, u32 n_buckets, u32 M,
+                        u32 *__restrict__ bucket_sums, u32 *__restrict__ chunk_sums) {
+    __shared__ __attribute__((aligned(16))) u32 stage[4 * 6 * 256];      // [wave][piece][lane][4 words]
+    wave_priority_high();
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 *wbase = stage + wave * (6 * 256);
+    const u32 *mine = wbase + 4 * lane;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = offsets[n_buckets];
+    u64 start64 = (u64)t * M;
+    if (start64 >= total) return;
+    u32 start = (u32)start64, stop = (total - start < M) ? total : start + M;
+    u32 lo = 0, hi = n_buckets;
+    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (offsets[mid] <= start) lo = mid; else hi = mid; }
+    u32 b = lo, bend = offsets[b + 1];
+    bool began_before = offsets[b] < start;
+    ge acc = ge_identity();
+    // an index that does not name a point (never the case for a consistent sort) requests record 0 and is skipped
+    auto request = [&](u32 e) -> bool {
+        const u32 idx = e & 0x7fffffffu;
+        const bool valid = idx < n_points;
+        const u32 *src = niels + 32ull * (valid ? idx : 0);
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * j), (__attribute__((address_space(3))) void *)(wbase + 256 * j), 16, 0, 0);
+        return valid;
+    };
+    auto staged = [&](u32 field) -> fe {           // 0: y + x, 1: y - x, 2: 2dxy
+        u32 w[8];
+        const uint4 a = *(const uint4 *)(mine + 256 * (2 * field)), c = *(const uint4 *)(mine + 256 * (2 * field + 1));
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+        return fe_unpack(w);
+    };
+    u32 e_cur = sorted[start];
+    bool valid_cur = request(e_cur);
+    for (u32 k = start; k < stop; k++) {
+        const bool more = k + 1 < stop;
+        const u32 e_next = more ? sorted[k + 1] : 0u;
+        if (k >= bend) {                              // bucket b ended exactly at k
+            ge_store(began_before ? chunk_sums + 64ull * t : bucket_sums + 32ull * b, acc);
+            acc = ge_identity(); began_before = false;
+            do { b++; bend = offsets[b + 1]; } while (k >= bend);     // b < n_buckets since k < total
+        }
+        // the record of entry k has arrived in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool negative = (e_cur >> 31) != 0;
+        // p + q and p - q differ by which of (y + x, y - x) meets which factor and by the sign of the 2dxy product (taken on T)
+        const fe q_a = staged(negative ? 0u : 1u), q_b = staged(negative ? 1u : 0u), q_c = staged(2u);
+        fe A = fe_mul(fe_sub(acc.Y, acc.X), q_a);
+        fe Bp = fe_mul(fe_add(acc.Y, acc.X), q_b);
+        fe C = fe_mul(fe_pick(acc.T, fe_sub(fe_zero(), acc.T), negative), q_c);
+        // every read of the staged record has returned (the products above may be scheduled behind this point, their operands
+        // are in registers by now): the next record may overwrite it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bool valid_next = false;
+        if (more) valid_next = request(e_next);
+        if (valid_cur) {
+            auto D = fe_add(acc.Z, acc.Z);
+            acc = ge_from_completed(fe_sub(Bp, A), fe_sub(D, C), fe_add(D, C), fe_add(Bp, A));
+        }
+        e_cur = e_next; valid_cur = valid_next;
     }
     u32 *dst;
     if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
@@ -697,8 +782,13 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     MARK("msm_wait_points");
     for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
     MARK("msm_accumulate");
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, direct ? n_points : n, direct ? (const u32 *)nullptr : d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
-                       ws.buckets, ws.chunk_sums);
+    // entries that name point records take the form with the prefetched record in LDS (XHE_MSM_ACC_STAGED=0: the register form)
+    const char *staged_env = getenv("XHE_MSM_ACC_STAGED");
+    if ((direct || !d_term_point) && !(staged_env && staged_env[0] == '0'))
+        hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, direct ? n_points : n, ws.offsets, ws.sorted, (u32)n_buckets, p.M, ws.buckets, ws.chunk_sums);
+    else
+        hipLaunchKernelGGL(k_msm_accumulate_regs, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, direct ? n_points : n, direct ? (const u32 *)nullptr : d_term_point, n_points, ws.offsets, ws.sorted, (u32)n_buckets, p.M,
+                           ws.buckets, ws.chunk_sums);
     MARK("msm_merge");
     hipLaunchKernelGGL(k_msm_merge, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.offsets, (u32)n_buckets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);
     hipLaunchKernelGGL(k_msm_merge_big, dim3(std::min<u32>((big_cap + 3) / 4, 1024)), dim3(256), 0, st, ws.offsets, p.M, ws.chunk_sums, ws.buckets, ws.big_list, big_cap);

@@ -69,14 +69,14 @@ __device__ __forceinline__ u32 wd_mul(u32 f, u32 g, const wd_lane &L) {
     wd_mul_step<4>(h, f, g, g19, L); wd_mul_step<5>(h, f, g, g19, L); wd_mul_step<6>(h, f, g, g19, L); wd_mul_step<7>(h, f, g, g19, L);
     wd_mul_step<8>(h, f, g, g19, L); wd_mul_step<9>(h, f, g, g19, L);
     if (!L.live) h = 0;                                // the idle lanes accumulated limbs that slid past limb 9
-    // round 1: carries of up to 39 bits
+    // first carry pass: carries of up to 39 bits
     u64 c = h >> L.sh;
     u32 lo = (u32)h & L.mask;
     u32 c_lo = (u32)c, c_hi = (u32)(c >> 32);
     u64 c19 = (u64)c_lo * 19u + ((u64)(c_hi * 19u) << 32);
     u32 in_lo = wd_carry_in(c_lo, (u32)c19), in_hi = wd_carry_in(c_hi, (u32)(c19 >> 32));
     u64 h1 = (u64)lo + (((u64)in_hi << 32) | in_lo);
-    // round 2: carries below 2^18; the idle lanes received limb 9's carry and must not pass anything on
+    // second carry pass: carries below 2^18; the idle lanes received limb 9's carry and must not pass anything on
     u32 c1 = (u32)(h1 >> L.sh) & L.live;
     u32 lo1 = (u32)h1 & L.mask;
     return (lo1 + wd_carry_in(c1, c1 * 19u)) & L.live;
