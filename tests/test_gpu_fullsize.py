@@ -123,6 +123,22 @@ def test_full_batch_with_one_pass_sort(engine, batch, monkeypatch):
 
 
 @pytest.mark.timeout(600)
+def test_full_batch_with_register_accumulation(engine, batch, monkeypatch):
+    """The bucket accumulation keeps its prefetched record in LDS; the form with the record in registers (the one entries
+    that name terms take), forced here: same verdicts, same ledger."""
+    v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.setenv("XHE_MSM_ACC_STAGED", "0")
+    v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    assert (v0.accept, v1.accept) == (1, 1) and cts0 == cts1
+    rec = bytearray(batch.records)
+    rec[batch.offsets[2500] + 400] ^= 4
+    v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    monkeypatch.delenv("XHE_MSM_ACC_STAGED")
+    v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
+    assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
+
+
+@pytest.mark.timeout(600)
 def test_full_batch_cut_into_parts(engine, batch, monkeypatch):
     """Batches from 128 MiB of records on are verified in consecutive parts, each against the ledger the part before it left
     (1 024 senders here, every one with transactions in every part).  Forced on this batch with 4 and 7 parts: the ledger of
