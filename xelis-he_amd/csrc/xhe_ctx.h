@@ -160,8 +160,10 @@ struct xhe_ctx {
     stage_timer timer;
     dev_pool pool;                 // blocks of freed batches
     xhe::host_batch spare_host; std::mutex spare_mu;   // host tables of a freed batch, kept for their memory
+    xhe::ingest_workers workers;   // host threads of the uploads' parsing (started by the first upload)
     void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
-    u32 *verdict_host = nullptr;                     // 64 pinned bytes the verdict words are read back into
+    u32 *verdict_host = nullptr;                     // pinned memory the verdict words are read back into: a ring of 64-byte slots
+    u32 verdict_next = 0;                            // the next slot of that ring
     // level-0 workspace
     dev_buf in_bytes, scalars, niels, ok, result, xyzt;
     msm_workspace msm;
@@ -172,7 +174,6 @@ struct xhe_ctx {
     u32 static_cap = 0;        // generators per side currently held
     dev_buf gen_tab;           // 32 x 256 fixed-base table of every static point (static_cap <= GEN_TABLE_CAP_MAX), else empty
     u32 gen_tab_cap = 0;       // the capacity gen_tab was built for, 0 = none
-    dev_buf static_partials, static_sum;
     bool tables_ready = false;
     unsigned char *static_scratch = nullptr;   // this device's copy of `scratch`
 };

@@ -18,6 +18,9 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -106,10 +109,57 @@ struct host_batch {
     void trade_storage(host_batch &o) { ex_txs.trade_storage(o.ex_txs); ex_xfs.trade_storage(o.ex_xfs); ex_cms.trade_storage(o.ex_cms); }
 };
 
-// fn(lo, hi) over [0, count) on up to `threads` host threads (the calling thread takes the first range)
+// Host threads that stay with a context between uploads: starting fifteen threads costs more than a pass of the ingest over a
+// few thousand records takes.  run(parts, fn) calls fn(1) .. fn(parts - 1) on the workers and fn(0) on the calling thread and
+// returns when all are done; one caller at a time.
+struct ingest_workers {
+    std::vector<std::thread> threads;
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    const std::function<void(unsigned)> *job = nullptr;
+    u64 generation = 0; unsigned parts = 0, pending = 0; bool quit = false;
+    void start(unsigned n) {
+        for (unsigned t = 0; t < n; t++)
+            threads.emplace_back([this, t]() {
+                u64 seen = 0;
+                for (;;) {
+                    const std::function<void(unsigned)> *fn;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_work.wait(lk, [&]() { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation; fn = job;
+                        if (t + 1 >= parts) continue;          // fewer parts than workers this time
+                    }
+                    (*fn)(t + 1);
+                    { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+                }
+            });
+    }
+    void run(unsigned n_parts, const std::function<void(unsigned)> &fn) {
+        if (n_parts > threads.size() + 1) n_parts = (unsigned)threads.size() + 1;
+        if (n_parts > 1) { { std::lock_guard<std::mutex> lk(mu); job = &fn; parts = n_parts; pending = n_parts - 1; generation++; } cv_work.notify_all(); }
+        fn(0);
+        if (n_parts > 1) { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&]() { return pending == 0; }); }
+    }
+    unsigned size() const { return (unsigned)threads.size(); }
+    ~ingest_workers() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_work.notify_all();
+        for (auto &th : threads) th.join();
+    }
+};
+
+// fn(lo, hi) over [0, count) on up to `threads` host threads (the calling thread takes the first range); with workers, on them
 template <typename F>
-static inline void ingest_parallel(u64 count, unsigned threads, F fn) {
+static inline void ingest_parallel(u64 count, unsigned threads, F fn, ingest_workers *workers = nullptr) {
     if (threads <= 1 || count < 2048) { if (count) fn((u64)0, count); return; }
+    if (workers && workers->size()) {
+        threads = std::min(threads, workers->size() + 1);
+        const u64 per = (count + threads - 1) / threads;
+        const std::function<void(unsigned)> part = [&](unsigned t) { const u64 lo = t * per, hi = std::min(count, lo + per); if (lo < hi) fn(lo, hi); };
+        workers->run(threads, part);
+        return;
+    }
     const u64 per = (count + threads - 1) / threads;
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < threads; t++) {
@@ -127,7 +177,7 @@ static inline unsigned ingest_thread_count() {
 }
 
 // returns false when a record is malformed (hb.structural says which) or the ledger view is inconsistent (hb.bad_ledger)
-static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv) {
+static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv, ingest_workers *workers = nullptr) {
     constexpr u32 NONE = 0xffffffffu;
     const unsigned threads = ingest_thread_count();
     static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
@@ -164,7 +214,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                     break;
                 }
             }
-        });
+        }, workers);
         if (first_bad.load() != ~0ull) { hb.structural = {0, XHE_ERR_MALFORMED, (int64_t)first_bad.load()}; return false; }
     }
     lap("records parsed");
@@ -244,7 +294,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 xf_cm[xf_base[i] + k] = same;
             }
         }
-    });
+    }, workers);
 
     lap("ledger look-ups");
     // ---- decode positions: one block per transaction, then the points shared between transactions ----
@@ -488,7 +538,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 hb.ex_xfs[xi] = x;
             }
         }
-    });
+    }, workers);
 
     lap("descriptors written");
     // ---- transcript tiles: transactions grouped by template (first appearance order), 64 per tile ----

@@ -131,4 +131,15 @@ void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_
     if (n_slots) hipLaunchKernelGGL(k_scan_final, dim3(grid_for(2 * n_slots, 256)), dim3(256), 0, st, slot_final, slot_base, n_slots, final_cts);
 }
 
+// The ciphertexts a batch leaves in the slots it used, written over the ledger's array of all ciphertexts (64 bytes per balance,
+// in the ledger view's order): what the next part of a batch verified in consecutive parts starts from.
+__global__ void __launch_bounds__(256) k_ledger_carry(const u32 *__restrict__ final_cts, const u32 *__restrict__ slot_of_used, u32 n_slots, u32 *__restrict__ ledger_cts) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 16 * n_slots) return;
+    ledger_cts[16ull * slot_of_used[g >> 4] + (g & 15)] = final_cts[g];
+}
+void launch_ledger_carry(hipStream_t st, const u32 *final_cts, const u32 *slot_of_used, u32 n_slots, u32 *ledger_cts) {
+    if (n_slots) hipLaunchKernelGGL(k_ledger_carry, dim3(grid_for(16ull * n_slots, 256)), dim3(256), 0, st, final_cts, slot_of_used, n_slots, ledger_cts);
+}
+
 }  // namespace xhe

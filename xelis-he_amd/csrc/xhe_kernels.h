@@ -85,6 +85,7 @@ void launch_ledger_scan(hipStream_t st, const dev_op *ops, u32 n_ops, const u32 
                         u32 *slot_base, u32 *slot_final, u32 *emit_incl, const u32 *emit_slot, u32 n_emit, u32 emit_pt_base, u32 *pts, u8 *ok);
 // the slots' resulting ciphertexts as 64-byte encodings (read back by the caller, not by any kernel)
 void launch_ledger_final(hipStream_t st, const u32 *slot_final, const u32 *slot_base, u32 n_slots, u32 *final_cts);
+void launch_ledger_carry(hipStream_t st, const u32 *final_cts, const u32 *slot_of_used, u32 n_slots, u32 *ledger_cts);
 // descriptor expansion (xhe_k_expand.hip): see expand_args in xhe_verify_types.h
 void launch_expand(hipStream_t st, const expand_args &a);
 // proof scalars

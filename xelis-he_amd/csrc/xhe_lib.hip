@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string.h>
@@ -31,11 +32,11 @@ static __device__ __align__(256) unsigned char scratch[MSM_STATIC_BYTES];
 
 static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory per context, at most
 // xhe_verify_batch cuts a batch whose records reach twice this size into parts of about this size, at most SPLIT_PARTS_MAX
-// (verify_batch_split below).  Measured on 100 000 transactions of 8 transfers (390 MB): one piece 41 ms, 2 parts 35 ms,
-// 4 parts 32 ms, 6 parts 31 ms, 8 parts 32.5 ms -- every part adds about 1 ms of device time (the short kernels at the head and
-// the tail of a verification do not fill the chip).
+// (verify_batch_split below).  Measured on 100 000 transactions of 8 transfers (390 MB): one piece 39-41 ms, 4 parts 31 ms,
+// 6 parts 28-29 ms, 8 parts 30 ms, 12 parts 33 ms -- every part adds fixed host work to the one uploader thread.
 static constexpr u64 SPLIT_PART_BYTES = 64ull << 20;
 static constexpr u64 SPLIT_PARTS_MAX = 6;
+static constexpr u32 VERDICT_SLOTS = 4;              // verifications whose verdict words may be on their way to the host at once
 // From this batch size on the signatures get a stream of their own and start beside the transcripts (measured on the
 // 10 000-transaction batch: 1.53 ms against 1.59 ms with the signatures behind the bulk decode).  Smaller batches are pure
 // chains of short kernels and keep to three streams.  XHE_SIG_STREAM_MIN_TXS overrides it (the tests run either schedule on
@@ -51,11 +52,21 @@ struct xhe_batch {
     u64 rp_gemm_min_rows = ~0ull;
     dev_buf pts, ok, chal, scalars, term_point, gh, gh_sums, rp_ctx, rp_acc, rp_mat, rp_dig, rp_bins, rp_rho, tx_err, rp_err, ms_hash;
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
+    dev_buf static_partials, static_sum;       // the static generators' contribution to the multiscalar check (from the fixed-base tables)
+    dev_buf slot_of_used;                      // used slot -> index of its balance in the ledger view
     dev_buf arena_up, arena_ws, arena_bytes;   // the blocks every buffer above is a range of: uploaded tables, workspace, the byte buffer
     std::vector<u32> group_off;   // per lg: offset into group_txs
     hipEvent_t ev_uploaded = nullptr;   // fires on the copy stream when every table of the batch has arrived
+    hipEvent_t ev_done = nullptr;       // fires on the main stream when a verification's verdict words have been read back
+    hipEvent_t ev_carried = nullptr;    // fires on side stream 0 when the batch's resulting ciphertexts have been handed on (batches verified in parts)
+    u32 *verdict_words = nullptr;       // where in the context's pinned memory the verdict words of the verification in flight arrive
+    bool in_flight = false;             // a verification has been enqueued and not yet finished
+    bool trivial = false;               // ... of an empty batch
+    std::shared_lock<std::shared_mutex> tables_lock;     // held from a verification's first launch to its finish: its kernels read the context's tables
     bool verified_ok = false;
     void release() {
+        for (dev_buf *b : {&static_partials, &static_sum, &slot_of_used}) b->release();
+        for (hipEvent_t *e : {&ev_done, &ev_carried}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         for (dev_buf *b : {&ex_txs, &ex_xfs, &ex_cms, &ex_mss, &sh_decs, &sh_early, &sh_key, &ex_slot_pos, &ex_slot_base, &merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &rp_dig, &rp_bins, &rp_rho, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
                            &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
@@ -135,8 +146,6 @@ int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
         launch_build_fixed_table(st, ctx->static_pts.as<u32>() + 32ull * (2 + ctx->static_cap), tcap, 32u,
                                  ctx->gen_tab.as<u32>() + 32ull * (2ull + tcap) * 32 * 256);                                    // H_vec[0..tcap)
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, ctx->static_partials.reserve((n_bases * 32 / 256 + 2) * 128));
-        HIPCHK(ctx, ctx->static_sum.reserve(128));
         HIPCHK(ctx, hipStreamSynchronize(st));
         ctx->gen_tab_cap = tcap;
     }
@@ -144,6 +153,8 @@ int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
 }
 
 static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]);
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side);
+static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict);
 
 extern "C" {
 
@@ -163,7 +174,7 @@ xhe_ctx *xhe_create(int device_id) {
     ok = ok && hipEventCreateWithFlags(&ctx->ev_stage_free, hipEventDisableTiming) == hipSuccess && hipEventRecord(ctx->ev_stage_free, ctx->copy_stream) == hipSuccess;
     for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64 * VERDICT_SLOTS, hipHostMallocDefault) == hipSuccess;
     // the address of this device's copy of the static scratch array (the array's name itself is a host-side stand-in)
     if (ok && hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch)) != hipSuccess) { ctx->static_scratch = nullptr; ok = false; }
     if (!ok) { g_create_error = "creating the HIP streams, events and read-back buffer failed"; xhe_destroy(ctx); return nullptr; }
@@ -175,7 +186,7 @@ void xhe_destroy(xhe_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->copy_stream}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
-                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab, &ctx->static_partials, &ctx->static_sum})
+                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab})
         b->release();
     ctx->pool.drain();
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -316,6 +327,7 @@ void xhe_batch_free(xhe_ctx *ctx, xhe_batch *b) {
         if (b->ev_uploaded) (void)hipEventSynchronize(b->ev_uploaded);
         for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
     }
+    if (b->tables_lock.owns_lock()) b->tables_lock.unlock();
     b->release();
     if (ctx) { std::lock_guard<std::mutex> lk(ctx->spare_mu); ctx->spare_host.trade_storage(b->hb); }
     delete b;
@@ -323,15 +335,21 @@ void xhe_batch_free(xhe_ctx *ctx, xhe_batch *b) {
 
 // Copies a list of (destination, source, bytes) on several host threads, in chunks of a few megabytes.
 struct copy_task { char *dst; const char *src; size_t bytes; };
-static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threads) {
-    constexpr size_t CHUNK = 4u << 20;
+static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threads, ingest_workers *workers = nullptr) {
+    const bool pooled = workers && workers->size() && threads > 1;      // the context's idle ingest threads: worth it from a megabyte on
+    const size_t CHUNK = pooled ? (1u << 20) : (4u << 20);
     std::vector<copy_task> tasks;
     size_t total = 0;
     for (auto &t : tasks_in)
         for (size_t o = 0; o < t.bytes; o += CHUNK) { tasks.push_back({t.dst + o, t.src + o, std::min(CHUNK, t.bytes - o)}); total += tasks.back().bytes; }
-    if (threads <= 1 || total < (8u << 20)) { for (auto &t : tasks) memcpy(t.dst, t.src, t.bytes); return; }
+    if (threads <= 1 || total < (pooled ? (1u << 20) : (8u << 20))) { for (auto &t : tasks) memcpy(t.dst, t.src, t.bytes); return; }
     std::atomic<size_t> next(0);
     auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= tasks.size()) break; memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes); } };
+    if (pooled) {
+        const std::function<void(unsigned)> part = [&](unsigned) { work(); };
+        workers->run(std::min<unsigned>(threads, (unsigned)tasks.size()), part);
+        return;
+    }
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
     work();
@@ -378,7 +396,8 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     const u64 n_signer_keys = in->n_multisig ? in->multisig_offsets[in->n_multisig] : 0;
     const u64 bytes_len = signers_base + 32 * n_signer_keys + 64, bytes_region = (256 + bytes_len + 255) & ~255ull;      // the transcript's word gather may read a few bytes in front of a record
     const bool early_bytes = bytes_region <= STAGE_MAX / 2;
-    if (hipEventCreateWithFlags(&B->ev_uploaded, hipEventDisableTiming) != hipSuccess) { set_error(ctx, "creating the batch's upload event failed"); delete B; return XHE_E_HIP; }
+    if (hipEventCreateWithFlags(&B->ev_uploaded, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&B->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&B->ev_carried, hipEventDisableTiming) != hipSuccess) { set_error(ctx, "creating the batch's events failed"); B->release(); delete B; return XHE_E_HIP; }
     std::thread copier;
     hipError_t copier_err = hipSuccess;
     B->arena_bytes.pool = &ctx->pool;
@@ -402,7 +421,8 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         });
     }
     auto join_copier = [&]() { if (copier.joinable()) copier.join(); };
-    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in);
+    if (!ctx->workers.size() && host_threads > 1) ctx->workers.start(host_threads - 1);
+    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in, &ctx->workers);
     lap("ingest");
     join_copier();
     lap("byte buffer staged and enqueued");
@@ -456,7 +476,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     UP(sig_keys, hb.sig_keys);
     UP(tmpl, hb.tmpl); UP(serial_txs, hb.serial_txs); UP(tr_list, hb.tr_list); UP(tr_tiles, hb.tr_tiles);
     UP(key_group_off, hb.key_group_off);
-    UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs);
+    UP(emit_slot, emit_slot); UP(ms_hash_tx, hb.ms_hash_tx); UP(group_txs, group_txs); UP(slot_of_used, hb.slot_of_used);
 #undef UP
     u64 n_slots = hb.slot_of_used.size();
     u64 n_ops = hb.n_ops;
@@ -484,6 +504,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
             else worst = std::max<u64>(worst, rp_matrix_part_rows(rows, lg) * (72ull << lg));
         }
         RS(rp_mat, worst); RS(rp_dig, dig); RS(rp_bins, bins); RS(rp_rho, 36ull * RP_GEMM_RHO_PARTS);
+        RS(static_partials, ((2ull + 2ull * GEN_TABLE_CAP_MAX) * 32 / 256 + 2) * 128); RS(static_sum, 128);
     }
 #undef RS
     auto fail = [&](const char *what, hipError_t e) { set_error(ctx, std::string(what) + ": " + hipGetErrorString(e)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; };
@@ -515,7 +536,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
                 size_t a = std::max(pc.off, lo), b = std::min(pc.off + pc.bytes, hi);
                 if (a < b && pc.src) tasks.push_back({(char *)ctx->stage + stage_off + (a - lo), (const char *)pc.src + (a - pc.off), b - a});
             }
-            parallel_copy(tasks, host_threads);
+            parallel_copy(tasks, host_threads, &ctx->workers);      // (the ingest is over: its threads are idle)
             if ((he = hipMemcpyAsync((char *)B->arena_up.p + lo, (char *)ctx->stage + stage_off, hi - lo, hipMemcpyHostToDevice, st)) != hipSuccess) return fail("uploading the batch tables", he);
             if (hi < up_total && (he = hipStreamSynchronize(st)) != hipSuccess) return fail("uploading the batch tables", he);      // the staging memory is reused
             lo = hi;
@@ -675,7 +696,7 @@ int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *B, int32_t what, uint8_t *
 // The host's share of a call (parse, ledger look-ups, the ordered walk: 16 ms for 100 000 transactions of 8 transfers) runs
 // before the device has anything to do.  A large batch is therefore cut into consecutive parts that go through the
 // upload-beside-verification pipeline of xhe_verify_batches, each part verified against the ledger the part before it left:
-//  * the ciphertexts a part starts from are patched into its byte buffer on the device side of the upload (the host tables of a
+//  * the ciphertexts a part starts from are copied into its byte buffer on the device, behind its upload (the host tables of a
 //    part depend on the ledger's keys and slots only, never on ciphertext values, so its upload need not wait);
 //  * the verdict is the reference's (verify.rs:492-514): the per-transaction error with the lowest index, else GenericProof,
 //    else RangeProof, a MIN over one key per part; a malformed record anywhere comes before all of them, as in the uncut path
@@ -708,6 +729,15 @@ static u64 split_verdict_key(const xhe_verdict &v, u64 base) {
     return (stage << 60) | (index << 8) | ((u64)v.err_code & 0xff);
 }
 
+// a batch whose verification has finished (its events have fired) goes back to the pool without draining the streams: the next
+// part's verification is running on them
+static void batch_free_finished(xhe_ctx *ctx, xhe_batch *b) {
+    if (b->tables_lock.owns_lock()) b->tables_lock.unlock();
+    b->release();
+    { std::lock_guard<std::mutex> lk(ctx->spare_mu); ctx->spare_host.trade_storage(b->hb); }
+    delete b;
+}
+
 // returns 1 when the call has to start over uncut (see above), else what xhe_verify_batch returns
 static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, const xhe_ledger_out *out,
                                   xhe_verdict *verdict, const uint8_t rng_seed[32], u32 n_parts) {
@@ -726,11 +756,31 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
             lo = hi;
         }
     }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // The ledger's ciphertexts as the parts so far left them, on the device: every part writes the slots it used into it
+    // (side stream 0, behind its ledger scan), the next part's byte buffer takes a copy in front of its own ledger decode on the
+    // same stream.  A part's verification is enqueued as soon as its upload is in, behind the part in front, which is finished
+    // (its verdict read) afterwards: the device goes from one part to the next without waiting for the host.
+    // XHE_SPLIT_OVERLAP=0: a part is enqueued only when the part in front has finished (the ledger passes through the host).
+    const char *overlap_env = getenv("XHE_SPLIT_OVERLAP");
+    const bool overlap = !(overlap_env && overlap_env[0] == '0');
+    hipStream_t s0 = ctx->side[0];
+    dev_buf ledger; ledger.pool = &ctx->pool;
+    struct release_ledger { xhe_ctx *c; dev_buf &b; ~release_ledger() { for (hipStream_t s : {c->stream, c->side[0]}) (void)hipStreamSynchronize(s); b.release(); } } ledger_guard{ctx, ledger};
+    if (overlap && in->n_balances) {
+        HIPCHK(ctx, ledger.reserve(64 * in->n_balances));
+        HIPCHK(ctx, hipMemcpyAsync(ledger.p, in->balance_cts, 64 * in->n_balances, hipMemcpyHostToDevice, s0));
+    }
+    const int timing_level = ctx->timer.level;
+    if (overlap) ctx->timer.level = 0;              // stage times are per verification; two are in flight here
+    struct restore_level { stage_timer &t; int level; ~restore_level() { t.level = level; } } level_guard{ctx->timer, timing_level};
+
     std::mutex mu; std::condition_variable cv;
     u32 uploaded = 0, verified = 0; bool stop = false, start_over = false;
     std::thread uploader([&]() {
         for (u32 k = 0; k < n_parts; k++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + 1; }); if (stop) return; }
+            // at most two parts ahead of the last finished one (one ahead of the one the device is working on)
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + (overlap ? 2 : 1); }); if (stop) return; }
             part &p = parts[k];
             p.rc = batch_upload_impl(ctx, records + offsets[p.lo], p.offs.data(), p.hi - p.lo, in, &p.B, &p.structural, false);
             const bool redo = p.rc == 0 && p.B && p.B->hb.multisig_updated && k + 1 < n_parts;
@@ -739,9 +789,10 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
             if (redo) return;
         }
     });
-    std::vector<u8> cur(in->balance_cts, in->balance_cts + 64 * in->n_balances);      // the ledger's ciphertexts as the parts so far left them
+    std::vector<u8> cur;                               // (without overlap) the ledger's ciphertexts as the parts so far left them
+    if (!overlap) cur.assign(in->balance_cts, in->balance_cts + 64 * in->n_balances);
     std::vector<int64_t> ms_set_by;
-    u64 key = ~0ull >> 1;
+    u64 key = ~0ull >> 1, malformed_key = ~0ull;      // a malformed record comes before every other error, whichever part holds it
     bool skip_verify = false;
     int32_t rc = 0;
     static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
@@ -749,68 +800,108 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     auto at = [&](u32 k, const char *what) {
         if (show_times) fprintf(stderr, "[xhe split] part %u %-20s at %.3f ms\n", k, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     };
+    auto mark_verified = [&](u32 k) { { std::lock_guard<std::mutex> lk(mu); verified = k + 1; } cv.notify_all(); };
+    // the verdict of an enqueued part; what it left in the ledger (host copy, without overlap); its batch back to the pool
+    auto finish_part = [&](u32 k) -> int32_t {
+        part &p = parts[k];
+        xhe_batch *B = p.B;
+        xhe_verdict v{1, XHE_OK, -1};
+        int32_t r = batch_verify_finish(ctx, B, &v);
+        at(k, "verified");
+        if (r == 0) {
+            const u64 vk = split_verdict_key(v, p.lo);
+            key = std::min(key, vk);
+            if (!v.accept && (vk >> 60) == 0) skip_verify = true;      // a per-transaction error: nothing behind it can come first but a malformed record
+            const host_batch &hb = B->hb;
+            if (!overlap && !skip_verify) {
+                // what this part left in the slots it used (also after a failed aggregate check: the reference has applied
+                // every transaction by then, verify.rs:492-498)
+                const u64 n_slots = hb.slot_of_used.size();
+                std::vector<u8> fin(64 * n_slots + 64);
+                hipError_t e = hipSuccess;
+                if (n_slots) { e = hipMemcpyAsync(fin.data(), B->final_cts.p, 64 * n_slots, hipMemcpyDeviceToHost, ctx->stream); if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); }
+                if (e != hipSuccess) { set_error(ctx, std::string("reading a part's ledger back: ") + hipGetErrorString(e)); r = XHE_E_HIP; }
+                else for (u64 u = 0; u < n_slots; u++) memcpy(cur.data() + 64ull * hb.slot_of_used[u], fin.data() + 64 * u, 64);
+            }
+            if (k + 1 == n_parts && hb.multisig_updated) {
+                ms_set_by = hb.multisig_set_by;
+                for (auto &x : ms_set_by) if (x >= 0) x += (int64_t)p.lo;
+            }
+        }
+        if (r == 0 && overlap) { hipError_t e = hipEventSynchronize(B->ev_carried); if (e != hipSuccess) { set_error(ctx, std::string("waiting for a part's ledger: ") + hipGetErrorString(e)); r = XHE_E_HIP; } }
+        if (r == 0) { batch_free_finished(ctx, B); p.B = nullptr; }     // (after an error the batch is freed below, behind a drain of the streams)
+        at(k, "freed");
+        mark_verified(k);
+        return r;
+    };
+    int64_t in_flight = -1;                            // the part whose verification is enqueued and not finished
     for (u32 k = 0; k < n_parts && rc == 0; k++) {
-        bool redo;
+        bool redo, ready;
+        { std::lock_guard<std::mutex> lk(mu); ready = uploaded > k; }
+        // The part's upload is not in yet: the part in flight is finished first.  (The device would run dry behind it anyway; and
+        // an upload that has to rebuild the context's tables for larger proofs waits for the verifications in flight.)
+        if (!ready && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; if (rc != 0) break; }
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); redo = start_over; }
         at(k, "uploaded");
         part &p = parts[k];
         rc = p.rc;
         if (rc == 0 && redo) { rc = 1; break; }
-        if (rc == 0 && !p.structural.accept) { key = split_verdict_key(p.structural, p.lo); break; }
+        if (rc == 0 && !p.structural.accept) { malformed_key = split_verdict_key(p.structural, p.lo); break; }
+        if (rc == 0 && !overlap && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
         if (rc == 0 && !skip_verify) {
             xhe_batch *B = p.B;
+            const host_batch &hb = B->hb;
             if (k > 0 && in->n_balances) {
-                // the ciphertexts this part starts from, behind its upload and in front of its verification
-                hipError_t e = hipSetDevice(ctx->device);
-                if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, B->ev_uploaded, 0);
-                if (e == hipSuccess) e = hipMemcpyAsync(B->bytes.as<u8>() + B->hb.cts_base, cur.data(), 64 * in->n_balances, hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                // the ciphertexts this part starts from, behind its upload and in front of its ledger decode
+                hipError_t e = hipStreamWaitEvent(s0, B->ev_uploaded, 0);
+                if (e == hipSuccess) e = overlap ? hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, ledger.p, 64 * in->n_balances, hipMemcpyDeviceToDevice, s0)
+                                                 : hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, cur.data(), 64 * in->n_balances, hipMemcpyHostToDevice, s0);
+                if (e == hipSuccess && !overlap) e = hipStreamSynchronize(s0);
                 if (e != hipSuccess) { set_error(ctx, std::string("handing the ledger to the next part of the batch: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
             }
-            xhe_verdict v{1, XHE_OK, -1};
             u8 seed[32]; memcpy(seed, rng_seed, 32); seed[31] ^= (u8)k; seed[30] ^= (u8)(k >> 8);      // independent batch factors per part
-            at(k, "ledger handed over");
-            if (rc == 0) rc = xhe_batch_verify(ctx, B, &v, seed);
-            at(k, "verified");
-            if (rc == 0) {
-                const u64 vk = split_verdict_key(v, p.lo);
-                key = std::min(key, vk);
-                if (!v.accept && (vk >> 60) == 0) skip_verify = true;      // a per-transaction error: nothing behind it can come first but a malformed record
-                else {
-                    // what this part left in the slots it used (also after a failed aggregate check: the reference has applied
-                    // every transaction by then, verify.rs:492-498)
-                    const host_batch &hb = B->hb;
-                    const u64 n_slots = hb.slot_of_used.size();
-                    std::vector<u8> fin(64 * n_slots + 64);
-                    hipError_t e = hipSuccess;
-                    if (n_slots) { e = hipMemcpyAsync(fin.data(), B->final_cts.p, 64 * n_slots, hipMemcpyDeviceToHost, ctx->stream); if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); }
-                    if (e != hipSuccess) { set_error(ctx, std::string("reading a part's ledger back: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
-                    else for (u64 u = 0; u < n_slots; u++) memcpy(cur.data() + 64ull * hb.slot_of_used[u], fin.data() + 64 * u, 64);
-                    if (k + 1 == n_parts && hb.multisig_updated) {
-                        ms_set_by = hb.multisig_set_by;
-                        for (auto &x : ms_set_by) if (x >= 0) x += (int64_t)p.lo;
-                    }
-                }
+            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap);
+            if (rc == 0 && overlap) {
+                launch_ledger_carry(s0, B->final_cts.as<u32>(), B->slot_of_used.as<u32>(), (u32)hb.slot_of_used.size(), ledger.as<u32>());
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess) e = hipEventRecord(B->ev_carried, s0);
+                if (e != hipSuccess) { set_error(ctx, std::string("handing a part's ledger on: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
             }
+            at(k, "enqueued");
+            if (rc == 0 && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
+            if (rc == 0) in_flight = k;
+        } else if (rc == 0) {
+            // nothing to verify behind a per-transaction error: the part was parsed for malformed records only
+            if (in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
+            if (p.B) { xhe_batch_free(ctx, p.B); p.B = nullptr; }
+            mark_verified(k);
         }
-        at(k, "ledger read");
-        if (p.B) { xhe_batch_free(ctx, p.B); p.B = nullptr; }
-        at(k, "freed");
-        { std::lock_guard<std::mutex> lk(mu); verified = k + 1; }
-        cv.notify_all();
     }
+    if (rc == 0 && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
     uploader.join();
-    for (auto &p : parts) if (p.B) { xhe_batch_free(ctx, p.B); p.B = nullptr; }
+    // whatever is left (an early exit, an error): drain the streams once, then free
+    bool any_left = false;
+    for (auto &p : parts) if (p.B) any_left = true;
+    if (any_left) for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
+    for (auto &p : parts) if (p.B) { p.B->in_flight = false; xhe_batch_free(ctx, p.B); p.B = nullptr; }
     if (rc != 0) return rc;
+    if (malformed_key != ~0ull) key = malformed_key;
     if (key == ~0ull >> 1) *verdict = {1, XHE_OK, -1};
     else {
         const u64 index = (key >> 8) & ((1ull << 52) - 1);
         *verdict = {0, (int32_t)(key & 0xff), index == (1ull << 52) - 1 ? (int64_t)-1 : (int64_t)index};
     }
     if (!verdict->accept || !out) return 0;
-    if (out->balance_cts) memcpy(out->balance_cts, cur.data(), 64 * in->n_balances);
+    if (out->balance_cts && in->n_balances) {
+        if (overlap) {
+            std::vector<u8> fin(64 * in->n_balances);
+            HIPCHK(ctx, hipMemcpyAsync(fin.data(), ledger.p, 64 * in->n_balances, hipMemcpyDeviceToHost, s0));
+            HIPCHK(ctx, hipStreamSynchronize(s0));
+            memcpy(out->balance_cts, fin.data(), 64 * in->n_balances);
+        } else memcpy(out->balance_cts, cur.data(), 64 * in->n_balances);
+    }
     if (out->account_nonces) memmove(out->account_nonces, in->account_nonces, 8 * in->n_accounts);
     if (out->multisig_set_by) {
         if (ms_set_by.size() == in->n_accounts) memcpy(out->multisig_set_by, ms_set_by.data(), 8 * in->n_accounts);
@@ -878,13 +969,14 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
 
 }  // extern "C"
 
-// The launch sequence of one verification.  Everything is enqueued on the context's stream; the only
-// host synchronisation is the final 64-byte read-back of the verdict words.
-static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]) {
+// The launch sequence of one verification, without waiting for it: batch_verify_finish does.  A second batch's sequence may be
+// enqueued behind it before it has finished (every stream is a queue; what the two share beyond the streams -- the bucket
+// workspace -- is used on the main stream only).
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side) {
     const host_batch &hb = B->hb;
     hipStream_t st = ctx->stream;
-    B->verified_ok = false;
-    if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
+    B->verified_ok = false; B->in_flight = false; B->trivial = false;
+    if (!hb.structural.accept) return 0;
     const u32 n_txs = (u32)hb.n_txs, n_cm = hb.n_cm, n_xf = hb.n_xf, n_dec = hb.n_decs;
     const u32 n_ops = hb.n_ops, n_slots = (u32)hb.slot_of_used.size(), n_sigs = hb.n_sigs;
     const u32 n_parts = n_cm + n_xf + n_txs;
@@ -896,8 +988,16 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     auto host_mark = [&](const char *what) {
         if (host_times) fprintf(stderr, "[xhe enqueue] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
     };
-    std::shared_lock<std::shared_mutex> tables_lock(ctx->tables_mu);
+    B->tables_lock = std::shared_lock<std::shared_mutex>(ctx->tables_mu);
+    B->in_flight = true;
+    // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
+    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
+    // The fills that open a verification run on the main stream, or (setup_on_side: a batch verified in parts) on side stream 1,
+    // which is free long before the main stream has finished the part in front: the part's decoding and signatures then start
+    // beside the multiscalar check of the part before.
+    hipStream_t s_setup = (setup_on_side && !one_stream) ? ctx->side[1] : st;
     HIPCHK(ctx, hipStreamWaitEvent(st, B->ev_uploaded, 0));
+    if (s_setup != st) HIPCHK(ctx, hipStreamWaitEvent(s_setup, B->ev_uploaded, 0));
     HIPCHK(ctx, tm.mark("setup", st));
     {
         setup_jobs jobs;
@@ -915,14 +1015,14 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
         jobs.fill(B->pts.as<u32>() + 32ull * hb.emit_base, 0, 32ull * hb.n_emit);
         jobs.fill(B->verdict.p, 0xffffffffu, 4);
         jobs.fill(B->verdict.as<u32>() + 4, 0, 12);
-        launch_setup(st, jobs);
+        launch_setup(s_setup, jobs);
     }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_setup, s_setup));
+    if (s_setup != st) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_setup, 0));
     if (n_txs == 0) {
-        *verdict = {1, XHE_OK, -1};
-        B->verified_ok = true;
+        B->trivial = true;
         HIPCHK(ctx, tm.mark("end", st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        tm.finish();
+        HIPCHK(ctx, hipEventRecord(B->ev_done, st));
         return 0;
     }
     const u8 *bytes = B->bytes.as<u8>();
@@ -937,10 +1037,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     //   main     transcripts -> proof scalars -> multiscalar check -> verdict
     //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
     //   side 1   every other point of the batch (public keys included) -> signature points + hashing -> end of the signature hashes
-    // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
-    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
     hipStream_t s0 = one_stream ? st : ctx->side[0], s1 = one_stream ? st : ctx->side[1];
-    HIPCHK(ctx, hipEventRecord(ctx->ev_setup, st));
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
                       B->tr_stream.as<u64>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
@@ -961,6 +1058,8 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
                            B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
         HIPCHK(ctx, tm.close("ledger_scan", s0));
         HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));         // ledger inputs and the senders' new ciphertexts are in place
+        // the resulting ledger ciphertexts, for the caller and for the next part of a batch verified in parts
+        if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
         return 0;
     };
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
@@ -1022,13 +1121,12 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     launch_sc_sum_partial(ss, sum_blocks, gh, n_parts, 2u, B->gh_sums.as<u32>());
     launch_static_terms(ss, B->gh_sums.as<u32>(), sum_blocks, B->rp_acc.as<u32>(), hb.nm_cap, hb.static_term_off, scalars, term_point);
     if (use_tables) {
-        launch_static_eval(ss, ctx->gen_tab.as<u32>(), scalars + 8ull * hb.static_term_off, hb.nm_cap, ctx->gen_tab_cap, ctx->static_partials.as<u32>(),
-                           ctx->static_sum.as<u32>());
+        launch_static_eval(ss, ctx->gen_tab.as<u32>(), scalars + 8ull * hb.static_term_off, hb.nm_cap, ctx->gen_tab_cap, B->static_partials.as<u32>(),
+                           B->static_sum.as<u32>());
         HIPCHK(ctx, tm.close("static_scalars", ss));
         HIPCHK(ctx, hipEventRecord(ctx->ev_static_done, ss));
     }
-    // side 0 again: resulting ledger ciphertexts, point-validity errors (need every point)
-    if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+    // side 0 again: point-validity errors (need every point)
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_side_done[2], 0));
     launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
@@ -1037,7 +1135,7 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     // merged multiscalar check: sigma terms + range-proof terms (+ static generators, unless their sum comes from the tables)
     msm_deps deps;
     deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[2];
-    if (use_tables) { deps.extra_point = ctx->static_sum.as<u32>(); deps.extra_ready = ctx->ev_static_done; }
+    if (use_tables) { deps.extra_point = B->static_sum.as<u32>(); deps.extra_ready = ctx->ev_static_done; }
     int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps);
     if (rc) return rc;
     host_mark("multiscalar check enqueued");
@@ -1047,12 +1145,32 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     HIPCHK(ctx, tm.mark("verdict", st));
     launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
     HIPCHK(ctx, tm.mark("end", st));
-    u32 *host = ctx->verdict_host;
-    HIPCHK(ctx, hipMemcpyAsync(host, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
+    B->verdict_words = ctx->verdict_host + 16 * (ctx->verdict_next++ % VERDICT_SLOTS);
+    HIPCHK(ctx, hipMemcpyAsync(B->verdict_words, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(B->ev_done, st));
     host_mark("all enqueued");
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    host_mark("synchronised");
-    tm.finish();
+    return 0;
+}
+
+// Waits for the verification batch_verify_enqueue started and reads its verdict; when a proof is wrong, decides which error the
+// reference reports with a second, sigma-only check.
+static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
+    const host_batch &hb = B->hb;
+    hipStream_t st = ctx->stream;
+    if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
+    struct unlock_on_exit { xhe_batch *b; ~unlock_on_exit() { b->in_flight = false; if (b->tables_lock.owns_lock()) b->tables_lock.unlock(); } } unlock{B};
+    if (!B->in_flight) { set_error(ctx, "no verification of this batch is in flight"); return XHE_E_ARG; }
+    HIPCHK(ctx, hipEventSynchronize(B->ev_done));
+    ctx->timer.finish();
+    if (B->trivial) { *verdict = {1, XHE_OK, -1}; B->verified_ok = true; return 0; }
+    const u32 n_txs = (u32)hb.n_txs, n_cm = hb.n_cm, n_xf = hb.n_xf;
+    const u8 *bytes = B->bytes.as<u8>();
+    const dev_tx *txs = B->txs.as<dev_tx>(); const dev_cm *cms = B->cms.as<dev_cm>(); const dev_xfer *xfers = B->xfers.as<dev_xfer>();
+    u32 *pts = B->pts.as<u32>(); u32 *chal = B->chal.as<u32>(); u32 *scalars = B->scalars.as<u32>();
+    u32 *term_point = B->term_point.as<u32>(); u32 *gh = B->gh.as<u32>(); u32 *rp_err = B->rp_err.as<u32>();
+    const u32 *sd = B->seed.as<u32>();
+    int32_t rc = 0;
+    const u32 *host = B->verdict_words;
     u64 first_err = (u64)host[0] | ((u64)host[1] << 32);
     u32 first_rp = host[2], merged_identity = host[12];
     if (first_err != ~0ull) { *verdict = {0, (int32_t)(first_err & 0xff), (int64_t)(first_err >> 32)}; return 0; }
@@ -1082,4 +1200,17 @@ static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdic
     }
     *verdict = {0, XHE_ERR_RANGE_PROOF, first_rp == 0xffffffffu ? (int64_t)-1 : (int64_t)first_rp};
     return 0;
+}
+
+// The launch sequence of one verification and its verdict.  Everything is enqueued on the context's streams; the only host
+// synchronisation is the wait for the 64-byte read-back of the verdict words.
+static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]) {
+    int32_t rc = batch_verify_enqueue(ctx, B, seed, false);
+    if (rc != 0) {
+        // an error return leaves in the middle of the launch sequence: nothing of it may still run when the caller goes on
+        for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
+        B->in_flight = false; if (B->tables_lock.owns_lock()) B->tables_lock.unlock();
+        return rc;
+    }
+    return batch_verify_finish(ctx, B, verdict);
 }
