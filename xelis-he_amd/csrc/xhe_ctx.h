@@ -161,6 +161,7 @@ struct xhe_ctx {
     dev_pool pool;                 // blocks of freed batches
     xhe::host_batch spare_host; std::mutex spare_mu;   // host tables of a freed batch, kept for their memory
     xhe::ingest_workers workers;   // host threads of the uploads' parsing (started by the first upload)
+    xhe::ingest_arena arena;       // memory of an upload's temporary host tables, kept between uploads
     void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
     u32 *verdict_host = nullptr;                     // pinned memory the verdict words are read back into: a ring of 64-byte slots
     u32 verdict_next = 0;                            // the next slot of that ring

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory_resource>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -109,6 +110,42 @@ struct host_batch {
     void trade_storage(host_batch &o) { ex_txs.trade_storage(o.ex_txs); ex_xfs.trade_storage(o.ex_xfs); ex_cms.trade_storage(o.ex_cms); }
 };
 
+// Memory of the ingest's temporary tables (some forty arrays of one entry per transaction, transfer or commitment), kept by
+// the context between uploads: fresh memory from the allocator costs a page fault per 4 KiB on first touch, on the one thread
+// that sizes the arrays -- more than the passes that fill them.  A bump allocator over blocks that are kept; reset() makes one
+// block of what the last use needed.
+struct ingest_arena : std::pmr::memory_resource {
+    struct block { char *p; size_t cap; };
+    std::vector<block> blocks;
+    size_t cur = 0, off = 0;
+    ~ingest_arena() override { for (auto &b : blocks) free(b.p); }
+    void reset() {
+        if (blocks.size() > 1) {
+            size_t total = 0;
+            for (auto &b : blocks) { total += b.cap; free(b.p); }
+            blocks.clear();
+            char *p = (char *)malloc(total);
+            if (p) blocks.push_back({p, total});
+        }
+        cur = 0; off = 0;
+    }
+    void *do_allocate(size_t bytes, size_t align) override {
+        if (align < 64) align = 64;
+        for (;; cur++, off = 0) {
+            if (cur == blocks.size()) {
+                const size_t cap = std::max<size_t>(bytes + align, std::max<size_t>(4u << 20, blocks.empty() ? 0 : 2 * blocks.back().cap));
+                char *p = (char *)malloc(cap);
+                if (!p) throw std::bad_alloc();
+                blocks.push_back({p, cap});
+            }
+            const size_t at = (((size_t)blocks[cur].p + off + align - 1) & ~(align - 1)) - (size_t)blocks[cur].p;
+            if (at + bytes <= blocks[cur].cap) { off = at + bytes; return blocks[cur].p + at; }
+        }
+    }
+    void do_deallocate(void *, size_t, size_t) override {}
+    bool do_is_equal(const std::pmr::memory_resource &o) const noexcept override { return this == &o; }
+};
+
 // Host threads that stay with a context between uploads: starting fifteen threads costs more than a pass of the ingest over a
 // few thousand records takes.  run(parts, fn) calls fn(1) .. fn(parts - 1) on the workers and fn(0) on the calling thread and
 // returns when all are done; one caller at a time.
@@ -177,7 +214,10 @@ static inline unsigned ingest_thread_count() {
 }
 
 // returns false when a record is malformed (hb.structural says which) or the ledger view is inconsistent (hb.bad_ledger)
-static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv, ingest_workers *workers = nullptr) {
+static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view &lv, ingest_workers *workers = nullptr,
+                                ingest_arena *arena = nullptr) {
+    std::pmr::memory_resource *mr = arena ? static_cast<std::pmr::memory_resource *>(arena) : std::pmr::new_delete_resource();
+    if (arena) arena->reset();
     constexpr u32 NONE = 0xffffffffu;
     const unsigned threads = ingest_thread_count();
     static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
@@ -196,7 +236,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     if (lv.n_multisig && lv.multisig_offsets[0] != 0) { hb.bad_ledger = true; return false; }
 
     // ---- pass A (parallel): parse every record ----
-    std::vector<tx_record> recs(n);
+    std::pmr::vector<tx_record> recs(n, mr);
     {
         std::atomic<u64> first_bad(~0ull);
         ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
@@ -246,7 +286,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     hb.multisig_set_by.assign(lv.n_accounts, -1);
 
     // ---- prefix sums over the shapes: transfers, commitments, terms, challenges, segments ----
-    std::vector<u32> xf_base(n + 1), cm_base(n + 1), cm_term(n), xf_term(n), seg_base(n + 1);
+    std::pmr::vector<u32> xf_base(n + 1, mr), cm_base(n + 1, mr), cm_term(n, mr), xf_term(n, mr), seg_base(n + 1, mr);
     {
         u32 x = 0, c = 0, term = 0, sg = 0;
         for (u64 i = 0; i < n; i++) {
@@ -261,9 +301,9 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     const u32 n_xf = xf_base[n], n_cm = cm_base[n];
 
     // ---- pass B (parallel): ledger look-ups of every transaction ----
-    std::vector<u32> src_acc(n), xf_acc(n_xf), xf_bal(n_xf), cm_bal(n_cm);
-    std::vector<u16> xf_cm(n_xf);                      // the source commitment with the transfer's asset (0xffff: none), so that the ordered walk reads no record bytes
-    std::vector<u64> cm_amount(n_cm);                  // plain amount leaving the slot besides the fee: burn, contract deposit
+    std::pmr::vector<u32> src_acc(n, mr), xf_acc(n_xf, mr), xf_bal(n_xf, mr), cm_bal(n_cm, mr);
+    std::pmr::vector<u16> xf_cm(n_xf, mr);                      // the source commitment with the transfer's asset (0xffff: none), so that the ordered walk reads no record bytes
+    std::pmr::vector<u64> cm_amount(n_cm, mr);                  // plain amount leaving the slot besides the fee: burn, contract deposit
     ingest_parallel(n, threads, [&](u64 lo, u64 hi) {
         for (u64 i = lo; i < hi; i++) {
             const tx_record &t = recs[i];
@@ -300,7 +340,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     // ---- decode positions: one block per transaction, then the points shared between transactions ----
     // block: range proof (4 + 2 lg) | source key if the ledger does not know it | per transfer C, D_s, D_r, Y_0, Y_1, Y_2 |
     // per commitment C_new, Y_0, Y_1, Y_2 | destination keys the ledger does not know
-    std::vector<u32> blk(n + 1), early_base(n + 1), key_base(n + 1), bulk_base(n + 1);
+    std::pmr::vector<u32> blk(n + 1, mr), early_base(n + 1, mr), key_base(n + 1, mr), bulk_base(n + 1, mr);
     {
         u32 p = 0, e = 0, k = 0, b = 0;
         for (u64 i = 0; i < n; i++) {
@@ -326,14 +366,14 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         (early == 1 ? shared_early : shared_key).push_back(pos);
         return pos;
     };
-    std::vector<u32> acc_pos(lv.n_accounts, NONE), acc_keyslot(lv.n_accounts, NONE), used_slot(lv.n_balances, NONE);
+    std::pmr::vector<u32> acc_pos(lv.n_accounts, NONE, mr), acc_keyslot(lv.n_accounts, NONE, mr), used_slot(lv.n_balances, NONE, mr);
     std::vector<u32> &slot_pos = hb.slot_pos; slot_pos.clear();
-    std::vector<u32> ops_count;                        // per used slot: operations so far (slot_pos: position of its initial C, D = +1)
+    std::pmr::vector<u32> ops_count(mr);                        // per used slot: operations so far (slot_pos: position of its initial C, D = +1)
     std::unordered_map<u64, u32> signer_pos;           // byte offset of a signer key -> position
     std::unordered_map<u32, u32> pos_keyslot;          // position of a signer / unknown-source key -> position in sig_keys
     struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
     std::vector<ms_cfg> cfgs;
-    std::vector<int32_t> cfg_of(lv.n_accounts, -1);
+    std::pmr::vector<int32_t> cfg_of(lv.n_accounts, -1, mr);
     for (u64 i = 0; i < lv.n_multisig; i++) {
         ms_cfg c; c.threshold = lv.multisig_threshold[i];
         for (u32 j = lv.multisig_offsets[i]; j < lv.multisig_offsets[i + 1]; j++) c.signer_off.push_back(hb.signers_base + 32ull * j);
@@ -358,10 +398,10 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         return s;
     };
     // what pass C leaves for pass D
-    std::vector<u32> src_pos(n), src_keyslot(n), sig_base(n + 1), step_err(n, ERRKEY_NONE), tmpl_of_tx(n), rp_row(n, 0), hash_idx(n, NONE);
-    std::vector<u32> cm_slot(n_cm, NONE), cm_local(n_cm, 0), xf_slot(n_xf, NONE), xf_local(n_xf, 0), xf_dest_pos(n_xf, NONE);
-    std::vector<u8> cm_fresh(n_cm, 0), xf_fresh(n_xf, 0);
-    std::vector<u32> key_cnt(lv.n_accounts, 0), src_keylocal(n), xf_keylocal(n_xf, NONE);      // terms on each account's key, and where a transaction's come in its run
+    std::pmr::vector<u32> src_pos(n, mr), src_keyslot(n, mr), sig_base(n + 1, mr), step_err(n, ERRKEY_NONE, mr), tmpl_of_tx(n, mr), rp_row(n, 0, mr), hash_idx(n, NONE, mr);
+    std::pmr::vector<u32> cm_slot(n_cm, NONE, mr), cm_local(n_cm, 0, mr), xf_slot(n_xf, NONE, mr), xf_local(n_xf, 0, mr), xf_dest_pos(n_xf, NONE, mr);
+    std::pmr::vector<u8> cm_fresh(n_cm, 0, mr), xf_fresh(n_xf, 0, mr);
+    std::pmr::vector<u32> key_cnt(lv.n_accounts, 0, mr), src_keylocal(n, mr), xf_keylocal(n_xf, NONE, mr);      // terms on each account's key, and where a transaction's come in its run
     std::vector<expand_ms> &ms_entries = hb.ex_mss; ms_entries.clear();       // co-signatures to verify, in transaction order
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_map;
     transcript_shape last_shape{255, 0, 0, 0, 0, 0}; u32 last_tmpl = TT_NONE;
@@ -468,7 +508,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     hb.n_emit = 2 * n_cm;
     hb.n_points = hb.emit_base + hb.n_emit;
     // challenges and range-proof terms follow in transaction order
-    std::vector<u32> chal_off(n), rp_term(n);
+    std::pmr::vector<u32> chal_off(n, mr), rp_term(n, mr);
     {
         u32 chal = 0, term = hb.sigma_terms;
         for (u64 i = 0; i < n; i++) {
@@ -479,7 +519,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         hb.n_chal = chal; hb.static_term_off = term; hb.n_terms = term + hb.n_static;
     }
     // runs of terms per account key (accounts with a single term need no merging)
-    std::vector<u32> key_run(lv.n_accounts, NONE);
+    std::pmr::vector<u32> key_run(lv.n_accounts, NONE, mr);
     {
         u32 o = 0;
         hb.key_group_off.clear();
@@ -488,7 +528,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
         hb.n_key_terms = o;
     }
     // co-signatures by transaction: ms_entries is in transaction order, so a transaction's entries follow its main signature
-    std::vector<u32> ms_first(n + 1, 0);
+    std::pmr::vector<u32> ms_first(n + 1, 0, mr);
     { for (auto &e : ms_entries) ms_first[e.tx + 1]++; for (u64 i = 0; i < n; i++) ms_first[i + 1] += ms_first[i]; }
     hb.emit_slot.assign(n_cm, 0);
     hb.ex_txs.resize(n); hb.ex_xfs.resize(n_xf); hb.ex_cms.resize(n_cm);
@@ -543,7 +583,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     lap("descriptors written");
     // ---- transcript tiles: transactions grouped by template (first appearance order), 64 per tile ----
     {
-        std::vector<u32> order;                       // template offsets in order of first appearance
+        std::pmr::vector<u32> order(mr);                       // template offsets in order of first appearance
         std::unordered_map<u32, std::vector<u32>> by_tmpl;
         u32 last_to = TT_NONE; std::vector<u32> *last_vec = nullptr;
         for (u64 i = 0; i < n; i++) {

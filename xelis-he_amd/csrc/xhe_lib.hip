@@ -422,7 +422,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     }
     auto join_copier = [&]() { if (copier.joinable()) copier.join(); };
     if (!ctx->workers.size() && host_threads > 1) ctx->workers.start(host_threads - 1);
-    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in, &ctx->workers);
+    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in, &ctx->workers, &ctx->arena);
     lap("ingest");
     join_copier();
     lap("byte buffer staged and enqueued");
@@ -836,11 +836,15 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     };
     int64_t in_flight = -1;                            // the part whose verification is enqueued and not finished
     for (u32 k = 0; k < n_parts && rc == 0; k++) {
-        bool redo, ready;
-        { std::lock_guard<std::mutex> lk(mu); ready = uploaded > k; }
-        // The part's upload is not in yet: the part in flight is finished first.  (The device would run dry behind it anyway; and
-        // an upload that has to rebuild the context's tables for larger proofs waits for the verifications in flight.)
-        if (!ready && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; if (rc != 0) break; }
+        bool redo;
+        // Whichever comes first: the part's upload (it is then enqueued behind the part in flight), or the end of the part in
+        // flight (it is then finished while the upload goes on -- an upload that has to rebuild the context's tables for larger
+        // proofs even waits for that).
+        while (in_flight >= 0) {
+            { std::unique_lock<std::mutex> lk(mu); if (cv.wait_for(lk, std::chrono::microseconds(50), [&]() { return uploaded > k; })) break; }
+            if (hipEventQuery(parts[(size_t)in_flight].B->ev_done) != hipErrorNotReady) { rc = finish_part((u32)in_flight); in_flight = -1; }
+        }
+        if (rc != 0) break;
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); redo = start_over; }
         at(k, "uploaded");
         part &p = parts[k];
