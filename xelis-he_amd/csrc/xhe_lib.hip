@@ -976,7 +976,7 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
 // The launch sequence of one verification, without waiting for it: batch_verify_finish does.  A second batch's sequence may be
 // enqueued behind it before it has finished (every stream is a queue; what the two share beyond the streams -- the bucket
 // workspace -- is used on the main stream only).
-static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side) {
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */) {
     const host_batch &hb = B->hb;
     hipStream_t st = ctx->stream;
     B->verified_ok = false; B->in_flight = false; B->trivial = false;
@@ -1062,8 +1062,9 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
                            B->slot_base.as<u32>(), B->slot_final.as<u32>(), B->emit_incl.as<u32>(), B->emit_slot.as<u32>(), n_cm, hb.emit_base, pts, ok);
         HIPCHK(ctx, tm.close("ledger_scan", s0));
         HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[0], s0));         // ledger inputs and the senders' new ciphertexts are in place
-        // the resulting ledger ciphertexts, for the caller and for the next part of a batch verified in parts
-        if (n_ops) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+        // a batch verified in parts: the next part waits for the resulting ledger ciphertexts (otherwise they are written at the
+        // end of this stream's work, off the path to the verdict)
+        if (n_ops && setup_on_side) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
         return 0;
     };
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
@@ -1130,7 +1131,8 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
         HIPCHK(ctx, tm.close("static_scalars", ss));
         HIPCHK(ctx, hipEventRecord(ctx->ev_static_done, ss));
     }
-    // side 0 again: point-validity errors (need every point)
+    // side 0 again: resulting ledger ciphertexts, point-validity errors (need every point)
+    if (n_ops && !setup_on_side) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_side_done[2], 0));
     launch_point_errors(s0, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
     HIPCHK(ctx, hipEventRecord(ctx->ev_points_checked, s0));
