@@ -117,3 +117,41 @@ def test_cut_batch_with_multisig_updates(engine, oracle):
         with _parts(k):
             got = _verify(engine, oracle, sb.view, blob, c_offs, len(order), gpu=True)
         assert got == ref, k
+
+
+def test_cut_batch_whose_later_part_needs_larger_tables(oracle):
+    """The first part holds range proofs over 2 values, the second over 16: its upload has to rebuild the context's generator
+    tables, which waits for the verification in flight -- the call must finish that part rather than wait for the upload.
+    A context of its own, so that the tables start small."""
+    import xelis_he_amd
+    from helpers import oracle_verify_batch
+    from xelis_he_amd.api import NATIVE, Account, Ledger, Transaction, TransactionBuilder, TransferBuilder
+    small = Account([(NATIVE, 1000)], "grow-small")
+    big = Account([(NATIVE, 1000)], "grow-big")
+    sink = Account([(NATIVE, 0)], "grow-sink")
+    ledger = Ledger([small, big, sink])
+    txs, state = [], ledger.clone()
+    for i in range(3):
+        tx = TransactionBuilder(1, small.pubkey, ("transfers", [TransferBuilder(sink.pubkey, 5)]), 1, 0).build(
+            {NATIVE: 1000 - 6 * i}, small.keypair, "grow-s%d" % i, state.get_account(small.pubkey))
+        tx.apply_without_verify(state)
+        txs.append(tx)
+    for i in range(2):
+        tx = TransactionBuilder(1, big.pubkey, ("transfers", [TransferBuilder(sink.pubkey, 1 + k) for k in range(8)]), 1, 0).build(
+            {NATIVE: 1000 - 37 * i}, big.keypair, "grow-b%d" % i, state.get_account(big.pubkey))
+        tx.apply_without_verify(state)
+        txs.append(tx)
+    ref_ledger = ledger.clone()
+    assert oracle_verify_batch(oracle, txs, ref_ledger) == (True, codes.OK, -1)
+    eng = xelis_he_amd.Engine(0)
+    try:
+        for k in (2, 5):
+            got = ledger.clone()
+            with _parts(k):
+                Transaction.verify_batch(eng, txs, got, seed="grow")
+            for key, a in ref_ledger.accounts.items():
+                assert got.accounts[key].balances == a.balances, k
+            eng.close()
+            eng = xelis_he_amd.Engine(0)          # cold tables again
+    finally:
+        eng.close()
