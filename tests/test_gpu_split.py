@@ -155,3 +155,22 @@ def test_cut_batch_whose_later_part_needs_larger_tables(oracle):
             eng = xelis_he_amd.Engine(0)          # cold tables again
     finally:
         eng.close()
+
+
+def test_cut_batch_reports_usage_errors(engine, oracle):
+    """A ledger view whose balance names an account that does not exist is a usage error of the call, cut or not; the context
+    stays usable afterwards."""
+    from xelis_he_amd.api import LedgerView, XheError
+    sb = SyntheticBatch(32, n_transfers=1, n_senders=2, seed=b"split-usage")
+    src = sb.view.contents
+    bad = LedgerView()
+    ctypes.memmove(ctypes.byref(bad), ctypes.byref(src), ctypes.sizeof(LedgerView))
+    accounts = (ctypes.c_uint32 * src.n_balances)(*[src.balance_account[i] for i in range(src.n_balances)])
+    accounts[src.n_balances - 1] = src.n_accounts + 7
+    bad.balance_account = accounts
+    for k in (1, 4):
+        with _parts(k):
+            with pytest.raises(XheError):
+                _verify(engine, oracle, ctypes.pointer(bad), sb.records, sb.offsets, sb.n_txs, gpu=True)
+            got = _verify(engine, oracle, sb.view, sb.records, sb.offsets, sb.n_txs, gpu=True)
+        assert got[0] == (1, codes.OK, -1), k
