@@ -131,3 +131,50 @@ extern "C" double xt_ingest(const u8 *records, const u64 *offsets, u64 n, const 
     out_counts[4] = hb.n_ops; out_counts[5] = hb.tr_tiles.size(); out_counts[6] = hb.n_chal; out_counts[7] = hb.tr_plan.stream_words;
     return sec;
 }
+
+// The same ingest on the threads and in the memory a context keeps between uploads (ingest_workers, ingest_arena), twice in a
+// row: the tables it lays out must not depend on either.  Returns 1 when both runs give the counts of the plain run.
+extern "C" int xt_ingest_pooled_matches(const u8 *records, const u64 *offsets, u64 n, const xhe_ledger_view *view) {
+    host_batch plain;
+    const bool ok0 = ingest_batch(plain, records, offsets, n, *view);
+    ingest_workers workers; workers.start(3);
+    ingest_arena arena;
+    for (int round = 0; round < 2; round++) {
+        host_batch hb;
+        const bool ok = ingest_batch(hb, records, offsets, n, *view, &workers, &arena);
+        if (ok != ok0 || hb.n_points != plain.n_points || hb.n_terms != plain.n_terms || hb.n_sigs != plain.n_sigs || hb.n_ops != plain.n_ops || hb.n_chal != plain.n_chal ||
+            hb.n_decs != plain.n_decs || hb.n_key_terms != plain.n_key_terms || hb.tr_list != plain.tr_list || hb.slot_of_used != plain.slot_of_used || hb.sig_keys != plain.sig_keys)
+            return 0;
+        if (hb.ex_txs.n != plain.ex_txs.n || (hb.ex_txs.n && memcmp(hb.ex_txs.p, plain.ex_txs.p, hb.ex_txs.n * sizeof(expand_tx)))) return 0;
+        if (hb.ex_xfs.n != plain.ex_xfs.n || (hb.ex_xfs.n && memcmp(hb.ex_xfs.p, plain.ex_xfs.p, hb.ex_xfs.n * sizeof(expand_xf)))) return 0;
+        if (hb.ex_cms.n != plain.ex_cms.n || (hb.ex_cms.n && memcmp(hb.ex_cms.p, plain.ex_cms.p, hb.ex_cms.n * sizeof(expand_cm)))) return 0;
+    }
+    return arena.blocks.size() <= 1 ? 1 : 2;       // (2: the arena did not settle on one block -- not an error of the tables)
+}
+
+// ingest_workers and ingest_arena on their own: ranges of a parallel pass cover [0, count) exactly once for every thread count up
+// to the pool's size and beyond; the arena hands out aligned, disjoint memory and keeps one block after reset().
+extern "C" int xt_pool_selftest() {
+    ingest_workers workers; workers.start(5);
+    for (unsigned threads = 1; threads <= 9; threads++)
+        for (u64 count : {0ull, 1ull, 2047ull, 2048ull, 100003ull}) {
+            std::vector<std::atomic<u32>> hits(count);
+            for (auto &h : hits) h.store(0);
+            ingest_parallel(count, threads, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; i++) hits[i].fetch_add(1); }, &workers);
+            for (auto &h : hits) if (h.load() != 1) return 0;
+        }
+    ingest_arena arena;
+    for (int round = 0; round < 3; round++) {
+        arena.reset();
+        std::vector<std::pair<char *, size_t>> got;
+        for (size_t bytes : {100ul, 5000000ul, 64ul, 9000000ul, 33ul}) {
+            char *p = (char *)arena.allocate(bytes, 16);
+            if (((size_t)p & 63) != 0) return 0;
+            memset(p, round, bytes);
+            for (auto &g : got) if (p < g.first + g.second && g.first < p + bytes) return 0;
+            got.push_back({p, bytes});
+        }
+        if (round > 0 && arena.blocks.size() != 1) return 0;
+    }
+    return 1;
+}

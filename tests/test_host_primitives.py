@@ -164,3 +164,16 @@ def test_ingest_layout_counts(hostlib):
     assert hostlib.xt_ingest(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, cnt) >= 0
     assert cnt[0] == 1 and cnt[3] == 32 + 2 * 2 * 2 and cnt[2] == 2 * 590 + 2 + 2 * 256      # co-signatures: 2 per co-signed transfer
     assert cnt[5] >= 5                                    # one transcript tile per shape at least
+
+
+def test_ingest_pool_and_arena(hostlib):
+    """The host threads and the memory a context keeps between uploads: a parallel pass covers its range exactly once for any
+    thread count, the arena hands out aligned disjoint memory and settles on one block; an ingest through both lays out the
+    tables of the plain ingest."""
+    import ctypes
+    hostlib.xt_pool_selftest.restype = ctypes.c_int
+    assert hostlib.xt_pool_selftest() == 1
+    from xelis_he_amd.api import SyntheticBatch
+    hostlib.xt_ingest_pooled_matches.restype = ctypes.c_int
+    for sb in (SyntheticBatch(64, seed=b"pooled-mixed", mixed=True), SyntheticBatch(24, n_transfers=3, n_senders=2, seed=b"pooled-chain")):
+        assert hostlib.xt_ingest_pooled_matches(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view) == 1
