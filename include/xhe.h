@@ -142,8 +142,9 @@ int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
                          const uint8_t rng_seed[32]);
 
 /* xhe_verify_batch over several independent batches (each against its own ledger snapshot, e.g. the blocks a node is catching up on),
- * pipelined inside the library: a helper thread parses and uploads batch k + 1 while batch k is verified, so the host work and the
- * host-to-device copy of one batch hide behind the GPU work of the one before.  verdicts[k] and batches[k].out are what
+ * pipelined inside the library: a helper thread parses and uploads the batches ahead while batch k is verified, and batch k + 1 is
+ * enqueued on the device behind batch k before batch k's verdict is read, so the host work, the host-to-device copy and the
+ * latency-bound start of one batch hide behind the GPU work of the one before.  verdicts[k] and batches[k].out are what
  * xhe_verify_batch would give for batch k alone.  Returns the first call-level error (the batches behind it are not verified). */
 typedef struct xhe_batch_args {
     const uint8_t *records; const uint64_t *offsets; uint64_t n_txs;

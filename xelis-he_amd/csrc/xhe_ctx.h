@@ -165,6 +165,7 @@ struct xhe_ctx {
     void *stage = nullptr; size_t stage_cap = 0;     // pinned host memory the uploads are assembled in
     u32 *verdict_host = nullptr;                     // pinned memory the verdict words are read back into: a ring of 64-byte slots
     u32 verdict_next = 0;                            // the next slot of that ring
+    u8 *readback[2] = {nullptr, nullptr}; size_t readback_cap[2] = {0, 0};   // pinned memory two batches' resulting ciphertexts are read back into (xhe_verify_batches)
     // level-0 workspace
     dev_buf in_bytes, scalars, niels, ok, result, xyzt;
     msm_workspace msm;

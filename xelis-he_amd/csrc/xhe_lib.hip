@@ -191,6 +191,7 @@ void xhe_destroy(xhe_ctx *ctx) {
     ctx->pool.drain();
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->verdict_host) (void)hipHostFree(ctx->verdict_host);
+    for (u8 *p : ctx->readback) if (p) (void)hipHostFree(p);
     ctx->timer.release();
     for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_stage_free) (void)hipEventDestroy(ctx->ev_stage_free);
@@ -841,7 +842,7 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
         // flight (it is then finished while the upload goes on -- an upload that has to rebuild the context's tables for larger
         // proofs even waits for that).
         while (in_flight >= 0) {
-            { std::unique_lock<std::mutex> lk(mu); if (cv.wait_for(lk, std::chrono::microseconds(50), [&]() { return uploaded > k; })) break; }
+            { std::unique_lock<std::mutex> lk(mu); if (cv.wait_for(lk, std::chrono::microseconds(200), [&]() { return uploaded > k; })) break; }
             if (hipEventQuery(parts[(size_t)in_flight].B->ev_done) != hipErrorNotReady) { rc = finish_part((u32)in_flight); in_flight = -1; }
         }
         if (rc != 0) break;
@@ -934,40 +935,114 @@ int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
     return rc;
 }
 
-// Transaction::verify_batch over several independent batches: a helper thread parses and uploads batch k + 1 (host work and
-// copies on the copy stream) while this thread verifies batch k, at most one batch ahead.
+// Transaction::verify_batch over several independent batches: a helper thread parses and uploads the batches ahead (host work
+// and copies on the copy stream) while this thread verifies.  Batch k + 1 is enqueued on the device as soon as its upload is in,
+// behind batch k, whose verdict is read afterwards (batch_verify_enqueue / batch_verify_finish): the latency-bound head of one
+// verification runs beside the tail of the one before.  The resulting ledger ciphertexts come back through pinned memory of
+// the context, copied on side stream 0 right behind the ledger scan, so that reading them does not wait for the batch behind.
+// XHE_BATCHES_OVERLAP=0: a batch is enqueued only when the batch before it has finished.
 int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_args *batches, xhe_verdict *verdicts) {
     if (!ctx || (n_batches && (!batches || !verdicts))) return XHE_E_ARG;
     for (uint64_t k = 0; k < n_batches; k++) if (!batches[k].offsets || !batches[k].in || !batches[k].rng_seed || (batches[k].n_txs && !batches[k].records)) return XHE_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const char *overlap_env = getenv("XHE_BATCHES_OVERLAP");
+    const bool overlap = !(overlap_env && overlap_env[0] == '0');
+    const int timing_level = ctx->timer.level;
+    if (overlap) ctx->timer.level = 0;              // stage times are per verification; two are in flight here
+    struct restore_level { stage_timer &t; int level; ~restore_level() { t.level = level; } } level_guard{ctx->timer, timing_level};
     std::vector<xhe_batch *> up(n_batches, nullptr);
     std::vector<int32_t> up_rc(n_batches, 0);
     std::mutex mu; std::condition_variable cv;
     uint64_t uploaded = 0, verified = 0; bool stop = false;
     std::thread uploader([&]() {
         for (uint64_t k = 0; k < n_batches; k++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + 1; }); if (stop) return; }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + (overlap ? 2 : 1); }); if (stop) return; }
             const xhe_batch_args &a = batches[k];
             up_rc[k] = batch_upload_impl(ctx, a.records, a.offsets, a.n_txs, a.in, &up[k], &verdicts[k], false);
             { std::lock_guard<std::mutex> lk(mu); uploaded = k + 1; }
             cv.notify_all();
         }
     });
+    auto mark_verified = [&](uint64_t k) { { std::lock_guard<std::mutex> lk(mu); verified = k + 1; } cv.notify_all(); };
+    static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto at = [&](uint64_t k, const char *what) {
+        if (show_times) fprintf(stderr, "[xhe batches] batch %llu %-12s at %.3f ms\n", (unsigned long long)k, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
+    };
+    hipStream_t s0 = ctx->side[0];
     int32_t rc = 0;
-    for (uint64_t k = 0; k < n_batches && rc == 0; k++) {
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); }
-        rc = up_rc[k];
-        if (rc == 0 && verdicts[k].accept) {
-            rc = xhe_batch_verify(ctx, up[k], &verdicts[k], batches[k].rng_seed);
-            if (rc == 0 && verdicts[k].accept && batches[k].out) rc = xhe_batch_read_ledger(ctx, up[k], batches[k].out);
+    // the verdict of an enqueued batch, its ledger, its memory back to the pool
+    auto finish_batch = [&](uint64_t k) -> int32_t {
+        xhe_batch *B = up[k];
+        int32_t r = batch_verify_finish(ctx, B, &verdicts[k]);
+        at(k, "verified");
+        if (r == 0) { hipError_t e = hipEventSynchronize(B->ev_carried); if (e != hipSuccess) { set_error(ctx, std::string("reading a batch's ledger back: ") + hipGetErrorString(e)); r = XHE_E_HIP; } }
+        const xhe_ledger_out *out = batches[k].out;
+        if (r == 0 && verdicts[k].accept && out) {
+            const host_batch &hb = B->hb;
+            const u8 *fin = ctx->readback[k & 1];
+            if (out->balance_cts) {
+                if (out->balance_cts != B->in_cts.data()) memmove(out->balance_cts, B->in_cts.data(), 64 * B->n_balances);
+                for (u64 u = 0; u < hb.slot_of_used.size(); u++) memcpy(out->balance_cts + 64ull * hb.slot_of_used[u], fin + 64 * u, 64);
+            }
+            if (out->account_nonces) memcpy(out->account_nonces, B->in_nonces.data(), 8 * B->n_accounts);
+            if (out->multisig_set_by) memcpy(out->multisig_set_by, hb.multisig_set_by.data(), 8 * B->n_accounts);
         }
-        if (up[k]) { xhe_batch_free(ctx, up[k]); up[k] = nullptr; }
-        { std::lock_guard<std::mutex> lk(mu); verified = k + 1; }
-        cv.notify_all();
+        if (r == 0) { batch_free_finished(ctx, B); up[k] = nullptr; }      // (after an error the batch is freed below, behind a drain of the streams)
+        mark_verified(k);
+        return r;
+    };
+    int64_t in_flight = -1;
+    for (uint64_t k = 0; k < n_batches && rc == 0; k++) {
+        // whichever comes first: the batch's upload, or the end of the batch in flight (an upload that has to rebuild the
+        // context's tables waits for the verifications in flight)
+        while (in_flight >= 0) {
+            { std::unique_lock<std::mutex> lk(mu); if (cv.wait_for(lk, std::chrono::microseconds(200), [&]() { return uploaded > k; })) break; }
+            if (hipEventQuery(up[(size_t)in_flight]->ev_done) != hipErrorNotReady) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
+        }
+        if (rc != 0) break;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); }
+        at(k, "uploaded");
+        rc = up_rc[k];
+        if (rc != 0) break;
+        if (!overlap && in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; if (rc != 0) break; }
+        xhe_batch *B = up[k];
+        if (!verdicts[k].accept) {
+            // malformed: the upload has said so; nothing to verify
+            if (in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
+            if (B) { xhe_batch_free(ctx, B); up[k] = nullptr; }
+            mark_verified(k);
+            continue;
+        }
+        rc = batch_verify_enqueue(ctx, B, batches[k].rng_seed, overlap);
+        if (rc == 0) {
+            // the resulting ciphertexts of the slots the batch used, into pinned memory (the slot of batch k - 2, long read)
+            const u64 n_slots = B->hb.slot_of_used.size();
+            hipError_t e = hipSuccess;
+            if (batches[k].out && n_slots) {
+                if (ctx->readback_cap[k & 1] < 64 * n_slots) {
+                    if (ctx->readback[k & 1]) (void)hipHostFree(ctx->readback[k & 1]);
+                    ctx->readback[k & 1] = nullptr; ctx->readback_cap[k & 1] = 0;
+                    e = hipHostMalloc((void **)&ctx->readback[k & 1], 64 * n_slots + 4096, hipHostMallocDefault);
+                    if (e == hipSuccess) ctx->readback_cap[k & 1] = 64 * n_slots + 4096;
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(ctx->readback[k & 1], B->final_cts.p, 64 * n_slots, hipMemcpyDeviceToHost, s0);
+            }
+            if (e == hipSuccess) e = hipEventRecord(B->ev_carried, s0);
+            if (e != hipSuccess) { set_error(ctx, std::string("reading a batch's ledger back: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
+        }
+        at(k, "enqueued");
+        if (rc == 0 && in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
+        if (rc == 0) in_flight = (int64_t)k;
     }
+    if (rc == 0 && in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
     uploader.join();
-    for (auto *b : up) if (b) xhe_batch_free(ctx, b);
+    bool any_left = false;
+    for (auto *b : up) if (b) any_left = true;
+    if (any_left) for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
+    for (auto *&b : up) if (b) { b->in_flight = false; xhe_batch_free(ctx, b); b = nullptr; }
     return rc;
 }
 
