@@ -64,10 +64,10 @@ const char *xhe_last_error(const xhe_ctx *ctx);
 int32_t xhe_msm_vartime(xhe_ctx *ctx, uint64_t n, const uint8_t *scalars32, const uint8_t *points32,
                         uint8_t out32[32], uint8_t *is_identity);
 
-/* xhe_msm_vartime for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc): same arguments and results, but the staging buffers and the whole workspace are ranges
- * of one file-scope device array of 12 MiB that every GPU the library runs on holds until the process ends; the call makes
- * no hipMalloc / hipFree.  No counterpart in the reference.  n above XHE_MSM_STATIC_MAX_TERMS (or a workspace that does not
+/* xhe_msm_vartime for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc):
+ * same arguments and results, but the staging buffers and the whole workspace are ranges of one file-scope device array of
+ * 12 MiB that every GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree.  It is
+ * not capturable into a HIP graph: it copies from and to the caller's host buffers and waits for its stream.  No counterpart in the reference.  n above XHE_MSM_STATIC_MAX_TERMS (or a workspace that does not
  * fit the array) is XHE_E_ARG with a message in xhe_last_error().  All calls on one GPU share that GPU's array, contexts
  * included: calls that overlap in time on one GPU race, so serialise them. */
 #define XHE_MSM_STATIC_MAX_TERMS 4096
@@ -145,7 +145,8 @@ int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
  * pipelined inside the library: a helper thread parses and uploads the batches ahead while batch k is verified, and batch k + 1 is
  * enqueued on the device behind batch k before batch k's verdict is read, so the host work, the host-to-device copy and the
  * latency-bound start of one batch hide behind the GPU work of the one before.  verdicts[k] and batches[k].out are what
- * xhe_verify_batch would give for batch k alone.  Returns the first call-level error (the batches behind it are not verified). */
+ * xhe_verify_batch would give for batch k alone.  Returns the first call-level error: the batches whose verification had not
+ * finished by then read {accept 0, XHE_ERR_STATE, -1} (never accept), and xhe_last_error() names the batch the call stopped at. */
 typedef struct xhe_batch_args {
     const uint8_t *records; const uint64_t *offsets; uint64_t n_txs;
     const xhe_ledger_view *in; const xhe_ledger_out *out;   /* out may be NULL */

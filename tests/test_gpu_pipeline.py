@@ -62,3 +62,50 @@ def test_pipelined_batches_equal_single_calls():
         assert (vs[n - 1].accept, vs[n - 1].err_code, vs[n - 1].first_bad_tx) == (0, codes.ERR_MALFORMED, 9)
     finally:
         engine.close()
+
+
+def test_call_level_error_leaves_no_unverified_accept():
+    """A call-level error in the middle of a run (a ledger view whose balance names an account that does not exist: XHE_E_ARG)
+    ends the call; the batches in front of it keep their verdicts, every batch from the failing one on reads reject -- an
+    unverified batch never reads accept -- and the error names the batch."""
+    import xelis_he_amd
+    from xelis_he_amd.api import LedgerView
+    engine = xelis_he_amd.Engine(0)
+    lib = engine.lib
+    lib.xhe_verify_batches.restype = ctypes.c_int32
+    try:
+        sbs = [SyntheticBatch(600, n_transfers=1, n_senders=16, seed=b"err-%d" % i, engine=engine) for i in range(5)]
+        bad = 2
+        n = len(sbs)
+        arr, keep = (BatchArgs * n)(), []
+        for i, sb in enumerate(sbs):
+            view = sb.view
+            if i == bad:
+                src = sb.view.contents
+                v = LedgerView()
+                for name, _ in LedgerView._fields_:
+                    setattr(v, name, getattr(src, name))
+                acc = (ctypes.c_uint32 * src.n_balances)(*[src.balance_account[j] for j in range(src.n_balances)])
+                acc[src.n_balances - 1] = src.n_accounts + 7            # out of range
+                v.balance_account = acc
+                keep += [v, acc]
+                view = ctypes.pointer(v)
+            arr[i].records, arr[i].offsets, arr[i].n_txs = sb.records, sb.offsets, sb.n_txs
+            arr[i].view, arr[i].out, arr[i].seed = ctypes.cast(view, ctypes.c_void_p), None, bytes([i + 1]) * 32
+        vs = (Verdict * n)()
+        for i in range(n):
+            vs[i].accept = 1                                             # whatever the caller's array held before
+        rc = lib.xhe_verify_batches(ctypes.c_void_p(engine.ctx), ctypes.c_uint64(n), arr, vs)
+        assert rc == -1                                                  # XHE_E_ARG
+        assert b"batch %d" % bad in lib.xhe_last_error(engine.ctx)
+        for i in range(bad):
+            assert vs[i].accept in (0, 1)                                # verified to the end, or rejected as unverified
+        assert vs[0].accept == 1                                         # long finished when batch 2's upload fails
+        for i in range(bad, n):
+            assert (vs[i].accept, vs[i].err_code, vs[i].first_bad_tx) == (0, codes.ERR_STATE, -1), i
+        # the context is still usable
+        v = Verdict()
+        engine._check(lib.xhe_verify_batch(engine.ctx, sbs[0].records, sbs[0].offsets, sbs[0].n_txs, sbs[0].view, None, ctypes.byref(v), b"\x05" * 32))
+        assert v.accept == 1
+    finally:
+        engine.close()

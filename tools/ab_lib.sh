@@ -1,12 +1,10 @@
 #!/bin/bash
-# A/B of library builds on one box: tools/ab_lib.sh A B[:ENV=value] ...  runs the headline batch with tools/variants/libxhe_<X>.so in turn
+# A/B of library builds on one box: tools/ab_lib.sh A B[:ENV=value] ...  runs the headline batch with tools/variants/libxhe_<X>.so in turn (selected through XHE_LIBRARY; the in-tree library is not touched)
 cd "$GRAFT_REPO_ROOT"
-cp xelis-he_amd/libxhe.so /tmp/libxhe_keep.so
 for rep in 1 2; do
   for spec in "$@"; do
     v=${spec%%:*}; e=""; [ "$spec" != "$v" ] && e=${spec#*:}
-    cp tools/variants/libxhe_$v.so xelis-he_amd/libxhe.so
-    env $e timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 0 --steps 30 --warmup 5 > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err || { tail -3 gpurun_out/ab_lib.err; cp /tmp/libxhe_keep.so xelis-he_amd/libxhe.so; exit 1; }
+    env XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" $e timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 0 --steps 30 --warmup 5 > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err || { tail -3 gpurun_out/ab_lib.err; exit 1; }
     python - "$spec" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_lib.json"))
@@ -14,4 +12,3 @@ print("variant", sys.argv[1], "rep", sys.argv[2], "ms_per_step", d["ms_per_step"
 PY
   done
 done
-cp /tmp/libxhe_keep.so xelis-he_amd/libxhe.so

@@ -1,11 +1,9 @@
 #!/bin/bash
 # A/B of library builds on the pipelined path: tools/ab_pipe.sh A B ...  (tools/variants/libxhe_<X>.so in turn, two rounds)
 cd "$GRAFT_REPO_ROOT"
-cp xelis-he_amd/libxhe.so /tmp/libxhe_keep.so
 for rep in 1 2; do
   for v in "$@"; do
-    cp tools/variants/libxhe_$v.so xelis-he_amd/libxhe.so
-    timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 2 --steps 5 --warmup 2 > gpurun_out/ab_pipe.json 2> gpurun_out/ab_pipe.err || { tail -3 gpurun_out/ab_pipe.err; cp /tmp/libxhe_keep.so xelis-he_amd/libxhe.so; exit 1; }
+    XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 2 --steps 5 --warmup 2 > gpurun_out/ab_pipe.json 2> gpurun_out/ab_pipe.err || { tail -3 gpurun_out/ab_pipe.err; exit 1; }
     python - "$v" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_pipe.json"))
@@ -14,4 +12,3 @@ print("variant", sys.argv[1], "rep", sys.argv[2], "single", e["ms_per_batch"], "
 PY
   done
 done
-cp /tmp/libxhe_keep.so xelis-he_amd/libxhe.so

@@ -10,7 +10,8 @@ class XheError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libxhe.so")
+    """The in-tree library, or the build XHE_LIBRARY names (A/B comparisons of two builds on one box)."""
+    return os.environ.get("XHE_LIBRARY") or os.path.join(_HERE, "libxhe.so")
 
 
 _lib = None

@@ -153,7 +153,8 @@ int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
 }
 
 static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]);
-static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side);
+static constexpr int32_t ENQUEUE_TABLES_BUSY = 2;
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side, bool may_block = true);
 static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict);
 
 extern "C" {
@@ -765,7 +766,8 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     // XHE_SPLIT_OVERLAP=0: a part is enqueued only when the part in front has finished (the ledger passes through the host).
     const char *overlap_env = getenv("XHE_SPLIT_OVERLAP");
     const bool overlap = !(overlap_env && overlap_env[0] == '0');
-    hipStream_t s0 = ctx->side[0];
+    // (XHE_ONE_STREAM, diagnostics: the verification's ledger work runs on the main stream, so the hand-over does too)
+    hipStream_t s0 = getenv("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];
     dev_buf ledger; ledger.pool = &ctx->pool;
     struct release_ledger { xhe_ctx *c; dev_buf &b; ~release_ledger() { for (hipStream_t s : {c->stream, c->side[0]}) (void)hipStreamSynchronize(s); b.release(); } } ledger_guard{ctx, ledger};
     if (overlap && in->n_balances) {
@@ -865,7 +867,11 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
                 if (e != hipSuccess) { set_error(ctx, std::string("handing the ledger to the next part of the batch: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
             }
             u8 seed[32]; memcpy(seed, rng_seed, 32); seed[31] ^= (u8)k; seed[30] ^= (u8)(k >> 8);      // independent batch factors per part
-            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap);
+            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, in_flight < 0);
+            if (rc == ENQUEUE_TABLES_BUSY) {
+                rc = finish_part((u32)in_flight); in_flight = -1;
+                if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, true);
+            }
             if (rc == 0 && overlap) {
                 launch_ledger_carry(s0, B->final_cts.as<u32>(), B->slot_of_used.as<u32>(), (u32)hb.slot_of_used.size(), ledger.as<u32>());
                 hipError_t e = hipGetLastError();
@@ -952,13 +958,20 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
     struct restore_level { stage_timer &t; int level; ~restore_level() { t.level = level; } } level_guard{ctx->timer, timing_level};
     std::vector<xhe_batch *> up(n_batches, nullptr);
     std::vector<int32_t> up_rc(n_batches, 0);
+    // A verdict counts only once its batch has been verified to the end (or found malformed by the upload): decided[k].  The
+    // uploads' structural verdicts (accept = 1 for a well-formed batch) land in a side array, never in the caller's, so that an
+    // error that ends the call early cannot leave an unverified batch reading "accept".
+    std::vector<xhe_verdict> structural(n_batches, xhe_verdict{0, XHE_ERR_STATE, -1});
+    std::vector<char> decided(n_batches, 0);
+    for (uint64_t k = 0; k < n_batches; k++) verdicts[k] = {0, XHE_ERR_STATE, -1};
+    int64_t failed_batch = -1;
     std::mutex mu; std::condition_variable cv;
     uint64_t uploaded = 0, verified = 0; bool stop = false;
     std::thread uploader([&]() {
         for (uint64_t k = 0; k < n_batches; k++) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + (overlap ? 2 : 1); }); if (stop) return; }
             const xhe_batch_args &a = batches[k];
-            up_rc[k] = batch_upload_impl(ctx, a.records, a.offsets, a.n_txs, a.in, &up[k], &verdicts[k], false);
+            up_rc[k] = batch_upload_impl(ctx, a.records, a.offsets, a.n_txs, a.in, &up[k], &structural[k], false);
             { std::lock_guard<std::mutex> lk(mu); uploaded = k + 1; }
             cv.notify_all();
         }
@@ -969,16 +982,17 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
     auto at = [&](uint64_t k, const char *what) {
         if (show_times) fprintf(stderr, "[xhe batches] batch %llu %-12s at %.3f ms\n", (unsigned long long)k, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     };
-    hipStream_t s0 = ctx->side[0];
+    hipStream_t s0 = getenv("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];      // (diagnostics: the ledger work of a verification is on the main stream then)
     int32_t rc = 0;
     // the verdict of an enqueued batch, its ledger, its memory back to the pool
     auto finish_batch = [&](uint64_t k) -> int32_t {
         xhe_batch *B = up[k];
-        int32_t r = batch_verify_finish(ctx, B, &verdicts[k]);
+        xhe_verdict v{0, XHE_ERR_STATE, -1};
+        int32_t r = batch_verify_finish(ctx, B, &v);
         at(k, "verified");
         if (r == 0) { hipError_t e = hipEventSynchronize(B->ev_carried); if (e != hipSuccess) { set_error(ctx, std::string("reading a batch's ledger back: ") + hipGetErrorString(e)); r = XHE_E_HIP; } }
         const xhe_ledger_out *out = batches[k].out;
-        if (r == 0 && verdicts[k].accept && out) {
+        if (r == 0 && v.accept && out) {
             const host_batch &hb = B->hb;
             const u8 *fin = ctx->readback[k & 1];
             if (out->balance_cts) {
@@ -988,7 +1002,8 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
             if (out->account_nonces) memcpy(out->account_nonces, B->in_nonces.data(), 8 * B->n_accounts);
             if (out->multisig_set_by) memcpy(out->multisig_set_by, hb.multisig_set_by.data(), 8 * B->n_accounts);
         }
-        if (r == 0) { batch_free_finished(ctx, B); up[k] = nullptr; }      // (after an error the batch is freed below, behind a drain of the streams)
+        if (r == 0) { verdicts[k] = v; decided[k] = 1; batch_free_finished(ctx, B); up[k] = nullptr; }      // (after an error the batch is freed below, behind a drain of the streams)
+        else if (failed_batch < 0) failed_batch = (int64_t)k;
         mark_verified(k);
         return r;
     };
@@ -1004,17 +1019,28 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); }
         at(k, "uploaded");
         rc = up_rc[k];
-        if (rc != 0) break;
+        if (rc != 0) {
+            // the batch in flight was enqueued before this upload failed: its verdict is still worth having
+            failed_batch = (int64_t)k;
+            if (in_flight >= 0) { (void)finish_batch((uint64_t)in_flight); in_flight = -1; }
+            break;
+        }
         if (!overlap && in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; if (rc != 0) break; }
         xhe_batch *B = up[k];
-        if (!verdicts[k].accept) {
+        if (!structural[k].accept) {
             // malformed: the upload has said so; nothing to verify
             if (in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
             if (B) { xhe_batch_free(ctx, B); up[k] = nullptr; }
+            verdicts[k] = structural[k]; decided[k] = 1;
             mark_verified(k);
             continue;
         }
-        rc = batch_verify_enqueue(ctx, B, batches[k].rng_seed, overlap);
+        rc = batch_verify_enqueue(ctx, B, batches[k].rng_seed, overlap, in_flight < 0);
+        if (rc == ENQUEUE_TABLES_BUSY) {
+            rc = finish_batch((uint64_t)in_flight); in_flight = -1;
+            if (rc == 0) rc = batch_verify_enqueue(ctx, B, batches[k].rng_seed, overlap, true);
+        }
+        if (rc != 0 && failed_batch < 0) failed_batch = (int64_t)k;
         if (rc == 0) {
             // the resulting ciphertexts of the slots the batch used, into pinned memory (the slot of batch k - 2, long read)
             const u64 n_slots = B->hb.slot_of_used.size();
@@ -1029,7 +1055,7 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
                 if (e == hipSuccess) e = hipMemcpyAsync(ctx->readback[k & 1], B->final_cts.p, 64 * n_slots, hipMemcpyDeviceToHost, s0);
             }
             if (e == hipSuccess) e = hipEventRecord(B->ev_carried, s0);
-            if (e != hipSuccess) { set_error(ctx, std::string("reading a batch's ledger back: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
+            if (e != hipSuccess) { set_error(ctx, std::string("reading a batch's ledger back: ") + hipGetErrorString(e)); rc = XHE_E_HIP; if (failed_batch < 0) failed_batch = (int64_t)k; }
         }
         at(k, "enqueued");
         if (rc == 0 && in_flight >= 0) { rc = finish_batch((uint64_t)in_flight); in_flight = -1; }
@@ -1043,6 +1069,13 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
     for (auto *b : up) if (b) any_left = true;
     if (any_left) for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]}) (void)hipStreamSynchronize(s);
     for (auto *&b : up) if (b) { b->in_flight = false; xhe_batch_free(ctx, b); b = nullptr; }
+    if (rc != 0) {
+        // every batch without a finished verification reads reject {0, XHE_ERR_STATE, -1} (set above); name the batch the call stopped at
+        for (uint64_t k = 0; k < n_batches; k++) if (!decided[k]) verdicts[k] = {0, XHE_ERR_STATE, -1};
+        std::string msg;
+        { std::lock_guard<std::mutex> lk(ctx->err_mu); msg = ctx->error; }
+        set_error(ctx, "xhe_verify_batches stopped at batch " + std::to_string((long long)failed_batch) + ": " + msg);
+    }
     return rc;
 }
 
@@ -1051,7 +1084,11 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
 // The launch sequence of one verification, without waiting for it: batch_verify_finish does.  A second batch's sequence may be
 // enqueued behind it before it has finished (every stream is a queue; what the two share beyond the streams -- the bucket
 // workspace -- is used on the main stream only).
-static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */) {
+// may_block = false (a caller that holds another verification in flight): when the context's tables are being rebuilt, or a
+// rebuild is waiting for the verifications in flight, the shared lock is not waited for -- ENQUEUE_TABLES_BUSY tells the caller to
+// finish what it has in flight (which lets the rebuild through) and to call again.  Waiting here instead would rely on the
+// lock letting new readers pass a waiting writer.
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */, bool may_block) {
     const host_batch &hb = B->hb;
     hipStream_t st = ctx->stream;
     B->verified_ok = false; B->in_flight = false; B->trivial = false;
@@ -1067,7 +1104,11 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     auto host_mark = [&](const char *what) {
         if (host_times) fprintf(stderr, "[xhe enqueue] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
     };
-    B->tables_lock = std::shared_lock<std::shared_mutex>(ctx->tables_mu);
+    if (may_block) B->tables_lock = std::shared_lock<std::shared_mutex>(ctx->tables_mu);
+    else {
+        B->tables_lock = std::shared_lock<std::shared_mutex>(ctx->tables_mu, std::try_to_lock);
+        if (!B->tables_lock.owns_lock()) return ENQUEUE_TABLES_BUSY;
+    }
     B->in_flight = true;
     // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
     static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
