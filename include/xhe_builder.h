@@ -86,6 +86,9 @@ xhe_synth *xhe_synth_transfers_gpu(xhe_ctx *ctx, uint64_t n_txs, uint32_t n_tran
 /* n_groups x 16 mixed transactions over disjoint account groups: 2 multisig set-ups, 4 one-asset transfers, 4 two-asset
  * double transfers, 2 native + 2 second-asset burns, 2 co-signed transfers from the accounts set up in the same group. */
 xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads);
+/* the same batch, byte for byte, with the range proofs generated on ctx's GPU, one xhe_range_proofs_prove call per shape
+ * (1, 2 and 4 value commitments; ctx == NULL: all on the CPU) */
+xhe_synth *xhe_synth_mixed_gpu(xhe_ctx *ctx, uint64_t n_groups, const uint8_t seed32[32], int32_t threads);
 void xhe_synth_free(xhe_synth *s);
 const uint8_t *xhe_synth_records(const xhe_synth *s, uint64_t *len);
 const uint64_t *xhe_synth_offsets(const xhe_synth *s, uint64_t *n_txs);

@@ -87,6 +87,8 @@ def _lib():
         lib.xhe_synth_transfers_gpu.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_mixed.restype = ctypes.c_void_p
         lib.xhe_synth_mixed.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
+        lib.xhe_synth_mixed_gpu.restype = ctypes.c_void_p
+        lib.xhe_synth_mixed_gpu.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_free.argtypes = [ctypes.c_void_p]
         lib.xhe_synth_records.restype = ctypes.c_void_p
         lib.xhe_synth_records.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -441,14 +443,14 @@ class SyntheticBatch:
     def __init__(self, n_txs, n_transfers=1, n_senders=1, seed=b"synthetic", threads=None, mixed=False, engine=None):
         """mixed=True: n_txs / 16 groups of mixed transactions (multisig set-ups, one- and two-asset transfers, burns,
         co-signed transfers) over disjoint account groups; n_transfers and n_senders are ignored.
-        engine: an Engine whose GPU generates the aggregated range proofs (transfer batches only; the records are the same
-        bytes as without it)."""
+        engine: an Engine whose GPU generates the aggregated range proofs (the records are the same bytes as without it)."""
         lib = _lib()
         threads = threads or min(os.cpu_count() or 1, 16)
         if mixed:
             if n_txs % 16:
                 raise ValueError("a mixed batch is made of groups of 16 transactions")
-            self.handle = lib.xhe_synth_mixed(n_txs // 16, _fresh_seed(seed), threads)
+            self.handle = (lib.xhe_synth_mixed_gpu(engine.ctx, n_txs // 16, _fresh_seed(seed), threads) if engine is not None
+                           else lib.xhe_synth_mixed(n_txs // 16, _fresh_seed(seed), threads))
         elif engine is not None:
             self.handle = lib.xhe_synth_transfers_gpu(engine.ctx, n_txs, n_transfers, n_senders, _fresh_seed(seed), threads)
         else:

@@ -311,9 +311,10 @@ xhe_synth *xhe_synth_transfers(uint64_t n_txs, uint32_t n_transfers, uint32_t n_
 // commitments), two native and two second-asset burns, and a co-signed transfer from each of the two multisig
 // accounts configured earlier in the same group.  Accounts per group: sender (both assets), receiver (both assets),
 // two multisig accounts, two co-signers.  Every transaction is built on the ledger left by its predecessors.
-xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads) {
+xhe_synth *xhe_synth_mixed_gpu(xhe_ctx *ctx, uint64_t n_groups, const uint8_t seed32[32], int32_t threads) {
     if (!n_groups || !seed32) return nullptr;
     if (threads < 1) threads = 1;
+    const bool on_gpu = ctx != nullptr;
     xhe_synth *S = new xhe_synth();
     drbg root(seed32);
     const u64 FUNDS = 1000000, ACC = 6, SLOTS = 8, TXS = 16;
@@ -344,7 +345,31 @@ xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t 
     std::vector<std::vector<u8>> recs(TXS * n_groups);
     std::vector<bytes32> seeds(n_groups);
     for (u64 g = 0; g < n_groups; g++) { u8 t[32]; root.bytes(t, 32); seeds[g] = b32(t); }
+    // With a GPU the range proofs are left out of the builder's pass (the builder's random generator skips their draws),
+    // proved together per shape on the device -- the sixteen transactions of a group carry 1, 2 or 4 value commitments --
+    // and patched in before the co-signatures and signatures, which cover them; the generator's counter at each
+    // transaction's first signing draw is kept, so the records are the same bytes as without a GPU.
+    // position in the group -> value commitments (a power of two), and its rank among the group's proofs of that shape
+    static const u32 shape_m[16] = {1, 1, 2, 2, 2, 2, 4, 4, 4, 4, 1, 1, 2, 2, 2, 2};
+    static const u32 shape_rank[16] = {0, 1, 0, 1, 2, 3, 0, 1, 2, 3, 2, 3, 4, 5, 6, 7};
+    static const u32 shape_per_group[3] = {4, 8, 4};            // m = 1, 2, 4
+    struct shape_inputs { std::vector<u8> transcripts, openings, seeds, proofs; std::vector<u64> values, ctr; };
+    shape_inputs sh[3];
+    std::vector<unsigned_tx> unsig(on_gpu ? TXS * n_groups : 0);
+    std::vector<u64> sign_ctr(on_gpu ? TXS * n_groups : 0);
+    if (on_gpu) for (u32 q = 0; q < 3; q++) {
+        const u64 cnt = shape_per_group[q] * n_groups, m = 1ull << q;
+        sh[q].transcripts.assign((size_t)XHE_RANGE_PROOF_TRANSCRIPT_BYTES * cnt, 0); sh[q].openings.resize(32 * m * cnt); sh[q].seeds.resize(32 * cnt);
+        sh[q].values.resize(m * cnt); sh[q].ctr.resize(cnt);
+    }
     std::atomic<u64> next_group(0); std::atomic<int> failed(0);
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {           // XHE_SYNTH_TIMES=1: phase times on stderr
+        if (!getenv("XHE_SYNTH_TIMES")) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[xhe synth mixed] %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     auto worker = [&]() {
         for (;;) {
             u64 g = next_group.fetch_add(1);
@@ -355,56 +380,121 @@ xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t 
             asset_balance sn{bytes32{}, FUNDS, {}}, s2{asset2, FUNDS, {}}, m0{bytes32{}, FUNDS, {}}, m1{bytes32{}, FUNDS, {}};
             memcpy(sn.ct.data(), &S->balance_cts[64 * (SLOTS * g + 0)], 64); memcpy(s2.ct.data(), &S->balance_cts[64 * (SLOTS * g + 1)], 64);
             memcpy(m0.ct.data(), &S->balance_cts[64 * (SLOTS * g + 4)], 64); memcpy(m1.ct.data(), &S->balance_cts[64 * (SLOTS * g + 5)], 64);
-            auto build = [&](builder_in &in, const keypair &src, std::vector<asset_balance *> bal, bool cosign) -> std::vector<u8> {
+            u64 base = TXS * g;
+            auto build = [&](u32 pos, builder_in &in, const keypair &src, std::vector<asset_balance *> bal, bool cosign) {
                 for (auto *b : bal) in.balances.push_back(*b);
-                unsigned_tx u; std::vector<asset_balance> nb;
-                if (build_unsigned(in, src, rng, u, &nb) != BUILD_OK) { failed = 1; return {}; }
-                for (auto &n : nb) for (auto *b : bal) if (b->asset == n.asset) *b = n;
-                if (cosign) {
-                    bytes32 h = u.hash();
-                    u.has_multisig = true;
-                    for (u8 c = 0; c < 2; c++) u.multisig.push_back({c, host::sign(k[4 + c], h.data(), 32, rng)});
+                std::vector<asset_balance> nb;
+                if (on_gpu) {
+                    pending_range_proof pend;
+                    unsigned_tx &u = unsig[base + pos];
+                    const u32 m = shape_m[pos], q = m == 1 ? 0 : m == 2 ? 1 : 2;
+                    if (build_unsigned(in, src, rng, u, &nb, &pend) != BUILD_OK || pend.values.size() != m) { failed = 1; return; }
+                    const u64 r = (u64)shape_per_group[q] * g + shape_rank[pos];
+                    u8 *ts = &sh[q].transcripts[(size_t)XHE_RANGE_PROOF_TRANSCRIPT_BYTES * r];
+                    memcpy(ts, pend.t.s.st.bytes, 200); ts[200] = pend.t.s.pos; ts[201] = pend.t.s.pos_begin;
+                    for (u32 j = 0; j < m; j++) { sh[q].values[(u64)m * r + j] = pend.values[j]; sc_tobytes(&sh[q].openings[32ull * (m * r + j)], pend.openings[j]); }
+                    memcpy(&sh[q].seeds[32 * r], pend.seed, 32); sh[q].ctr[r] = pend.ctr;
+                    sign_ctr[base + pos] = rng.ctr;
+                    rng.ctr += cosign ? 3 : 1;                    // the co-signers' nonces and the source's, drawn when the proof is in
+                } else {
+                    unsigned_tx u;
+                    if (build_unsigned(in, src, rng, u, &nb) != BUILD_OK) { failed = 1; return; }
+                    if (cosign) {
+                        bytes32 h = u.hash();
+                        u.has_multisig = true;
+                        for (u8 c = 0; c < 2; c++) u.multisig.push_back({c, host::sign(k[4 + c], h.data(), 32, rng)});
+                    }
+                    recs[base + pos] = u.sign(src, rng);
                 }
-                return u.sign(src, rng);
+                for (auto &n : nb) for (auto *b : bal) if (b->asset == n.asset) *b = n;
             };
             auto transfer = [&](const bytes32 &asset) { transfer_in tr; tr.asset = asset; tr.amount = 1; tr.dest = k[1].pub_bytes; return tr; };
-            u64 base = TXS * g;
             for (u32 j = 0; j < 2; j++) {             // multisig set-ups
                 builder_in in; in.type = 2; in.fee = 3; in.signers = {k[4].pub_bytes, k[5].pub_bytes}; in.threshold = 2;
-                recs[base + j] = build(in, k[2 + j], {j ? &m1 : &m0}, false);
+                build(j, in, k[2 + j], {j ? &m1 : &m0}, false);
             }
             for (u32 j = 0; j < 4; j++) {             // one transfer, one asset
                 builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{})};
-                recs[base + 2 + j] = build(in, k[0], {&sn}, false);
+                build(2 + j, in, k[0], {&sn}, false);
             }
             for (u32 j = 0; j < 4; j++) {             // two transfers, two assets
                 builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{}), transfer(asset2)};
-                recs[base + 6 + j] = build(in, k[0], {&sn, &s2}, false);
+                build(6 + j, in, k[0], {&sn, &s2}, false);
             }
             for (u32 j = 0; j < 4; j++) {             // burns: native, native, second asset, second asset
                 builder_in in; in.type = 1; in.fee = 3; in.burn_asset = j < 2 ? bytes32{} : asset2; in.burn_amount = 1;
-                recs[base + 10 + j] = j < 2 ? build(in, k[0], {&sn}, false) : build(in, k[0], {&sn, &s2}, false);
+                if (j < 2) build(10 + j, in, k[0], {&sn}, false); else build(10 + j, in, k[0], {&sn, &s2}, false);
             }
             for (u32 j = 0; j < 2; j++) {             // co-signed transfers from the multisig accounts
                 builder_in in; in.type = 0; in.fee = 3; in.transfers = {transfer(bytes32{})};
-                recs[base + 14 + j] = build(in, k[2 + j], {j ? &m1 : &m0}, true);
+                build(14 + j, in, k[2 + j], {j ? &m1 : &m0}, true);
             }
             if (failed) return;
         }
     };
     gens().ensure(64 * 4);
-    std::vector<std::thread> pool;
-    for (int i = 0; i < threads; i++) pool.emplace_back(worker);
-    for (auto &th : pool) th.join();
+    {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+    }
+    lap(on_gpu ? "transactions without range proofs" : "transactions");
+    if (!failed && on_gpu) {
+        for (u32 q = 0; q < 3 && !failed; q++) {
+            const u64 cnt = shape_per_group[q] * n_groups;
+            const u32 m = 1u << q, lg = 6 + q;
+            sh[q].proofs.resize((size_t)32 * (9 + 2 * lg) * cnt);
+            if (xhe_range_proofs_prove(ctx, cnt, m, sh[q].transcripts.data(), sh[q].values.data(), sh[q].openings.data(), sh[q].seeds.data(), sh[q].ctr.data(),
+                                       sh[q].proofs.data()) != 0) failed = 1;
+        }
+        lap("range proofs on the GPU");
+        std::atomic<u64> next_sign(0);
+        auto signer = [&]() {
+            for (;;) {
+                u64 g = next_sign.fetch_add(1);
+                if (g >= n_groups) break;
+                const keypair *k = keys[g].k;
+                for (u32 pos = 0; pos < TXS; pos++) {
+                    unsigned_tx &u = unsig[TXS * g + pos];
+                    const u32 m = shape_m[pos], q = m == 1 ? 0 : m == 2 ? 1 : 2;
+                    const size_t proof_bytes = 32 * (9 + 2 * (6 + q));
+                    if (u.rp_len != proof_bytes) { failed = 1; return; }
+                    memcpy(&u.preimage[u.rp_off], &sh[q].proofs[proof_bytes * ((u64)shape_per_group[q] * g + shape_rank[pos])], proof_bytes);
+                    drbg rng(seeds[g].data()); rng.ctr = sign_ctr[TXS * g + pos];
+                    const bool cosign = pos >= 14;
+                    if (cosign) {
+                        bytes32 h = u.hash();
+                        u.has_multisig = true;
+                        for (u8 c = 0; c < 2; c++) u.multisig.push_back({c, host::sign(k[4 + c], h.data(), 32, rng)});
+                    }
+                    const keypair &src = pos < 2 ? k[2 + pos] : pos >= 14 ? k[2 + (pos - 14)] : k[0];
+                    recs[TXS * g + pos] = u.sign(src, rng);
+                    u = unsigned_tx();
+                }
+            }
+        };
+        if (!failed) {
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(signer);
+            for (auto &th : pool) th.join();
+        }
+        lap("signatures");
+    }
     if (failed) { delete S; return nullptr; }
     S->offsets.push_back(0);
-    for (auto &r : recs) { S->records.insert(S->records.end(), r.begin(), r.end()); S->offsets.push_back(S->records.size()); }
+    {
+        size_t total = 0;
+        for (auto &r : recs) total += r.size();
+        S->records.reserve(total);
+    }
+    for (auto &r : recs) { S->records.insert(S->records.end(), r.begin(), r.end()); S->offsets.push_back(S->records.size()); std::vector<u8>().swap(r); }
     xhe_ledger_view &v = S->view;
     memset(&v, 0, sizeof v);
     v.n_accounts = ACC * n_groups; v.account_keys = S->account_keys.data(); v.account_nonces = S->nonces.data();
     v.n_balances = SLOTS * n_groups; v.balance_account = S->balance_account.data(); v.balance_assets = S->balance_assets.data(); v.balance_cts = S->balance_cts.data();
     return S;
 }
+xhe_synth *xhe_synth_mixed(uint64_t n_groups, const uint8_t seed32[32], int32_t threads) { return xhe_synth_mixed_gpu(nullptr, n_groups, seed32, threads); }
 void xhe_synth_free(xhe_synth *s) { delete s; }
 const uint8_t *xhe_synth_records(const xhe_synth *s, uint64_t *len) { if (len) *len = s->records.size(); return s->records.data(); }
 const uint64_t *xhe_synth_offsets(const xhe_synth *s, uint64_t *n_txs) { if (n_txs) *n_txs = s->offsets.size() - 1; return s->offsets.data(); }
