@@ -134,7 +134,7 @@ typedef struct xhe_verdict {
  * (the reference leaves its state half-updated), and an unknown account or asset is XHE_ERR_STATE (the
  * reference's mock ledger panics).  rng_seed seeds the batch-factor generator (the reference draws
  * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it.
- * A batch whose records reach 128 MiB is cut into consecutive parts inside the call (the host's parsing of part k + 1 runs
+ * A batch whose records reach 80 MiB is cut into consecutive parts inside the call (the host's parsing of part k + 1 runs
  * beside the device's verification of part k, every part against the ledger the part before it left); verdict, index and
  * ledger are those of the batch in one piece.  XHE_SPLIT_PARTS in the environment sets the number of parts (1: never cut). */
 int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
@@ -158,7 +158,8 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
  *
  * xhe_verify_batch_sharded is xhe_verify_batch over n_ctx contexts (one per GPU; the same device may appear twice): the batch is
  * cut along the connected components of its account graph (a transaction depends on every earlier one that touches its accounts,
- * verify.rs:301-341), every shard is verified by its own context against the same ledger snapshot on a thread of its own, and the
+ * verify.rs:301-341; into consecutive ranges when the components do not balance, see xhe_plan_shards), every shard is verified by its
+ * own context, on a thread of its own, against the accounts and balances of the ledger snapshot that its transactions name, and the
  * verdicts combine by the reference's precedence (first failing transaction in batch order, verify.rs:492-498, then GenericProof,
  * then RangeProof, verify.rs:500-514).  verdict, first_bad_tx (an index into the whole batch) and `out` are those of the
  * single-context call.  xhe_partition_batch exposes the cut (shard_of_tx[i] in [0, n_shards); returns 1 and the index when a record
@@ -166,6 +167,17 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
  * process-per-GPU driver all-reduces that one word (RCCL, MIN) instead of calling xhe_verify_batch_sharded. */
 int32_t xhe_partition_batch(const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, uint32_t n_shards, uint32_t *shard_of_tx,
                             int64_t *first_malformed);
+/* The cut xhe_verify_batch_sharded itself makes.  When the account groups do not balance -- the heaviest shard would carry more than
+ * 1.25 of the even share, e.g. the reference bench's single sender for every transaction (benches/tx.rs:129-189) -- and no
+ * transaction of the batch changes a multisig configuration, the batch is cut into n_shards consecutive ranges of equal weight
+ * instead (*consecutive_ranges = 1, shard_of_tx ascends): range s then has to start from the ledger the ranges in front of it leave
+ * (xhe_batch_apply range after range; xhe_batch_set_ledger hands the state to an uploaded range).  Otherwise as xhe_partition_batch.
+ * xhe_slice_shard copies one shard's records out of the batch (out_offsets: n_local + 1 entries, out_global_index: n_local;
+ * with all three output pointers NULL only the sizes are returned). */
+int32_t xhe_plan_shards(const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, uint32_t n_shards, uint32_t *shard_of_tx,
+                        int32_t *consecutive_ranges, int64_t *first_malformed);
+int32_t xhe_slice_shard(const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const uint32_t *shard_of_tx, uint32_t shard,
+                        uint8_t *out_records, uint64_t *out_offsets, uint64_t *out_global_index, uint64_t *n_local, uint64_t *n_bytes);
 int32_t xhe_verify_batch_sharded(xhe_ctx *const *ctxs, uint32_t n_ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,
                                  const xhe_ledger_view *in, const xhe_ledger_out *out, xhe_verdict *verdict, const uint8_t rng_seed[32]);
 /* global_index[k] = position in the whole batch of the shard's k-th transaction (n_local entries) */
@@ -180,6 +192,12 @@ int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *o
                          const xhe_ledger_view *in, xhe_batch **batch_out, xhe_verdict *structural_verdict);
 int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *batch, xhe_verdict *verdict, const uint8_t rng_seed[32]);
 int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *batch, const xhe_ledger_out *out);
+/* Replaces the ledger ciphertexts the uploaded batch starts from: balance_cts = n_balances x 64 bytes in the order of the ledger view
+ * the batch was uploaded with (keys, assets, nonces and multisig configurations stay).  The next xhe_batch_verify / xhe_batch_apply
+ * runs against them.  For callers that learn a batch's starting state after they uploaded it: xhe_verify_batch_sharded hands a
+ * consecutive range of a batch the ledger the ranges in front of it leave (the state every later transaction of
+ * Transaction::verify_batch sees, verify.rs:492-498).  The batch must not be in use by another call. */
+int32_t xhe_batch_set_ledger(xhe_ctx *ctx, xhe_batch *batch, const uint8_t *balance_cts);
 /* Transaction::apply_without_verify (/root/reference/src/tx/verify.rs:545-619) for every transaction of the uploaded
  * batch in order: only the Twisted-ElGamal ledger arithmetic (sender balance minus fee/burn/deposits and transfer
  * ciphertexts, receiver balance plus transfer ciphertext, elgamal.rs:280-377), no signature, nonce or proof check.
@@ -213,6 +231,15 @@ int32_t xhe_last_stage_times(const xhe_ctx *ctx, const char **names, float *ms, 
  * accumulation kernel), "after_accumulate" and "total", 0 nothing.  Every measured stage boundary is an event on
  * its stream; level 0 or 1 keeps them out of the launch sequence.  No counterpart in the reference (diagnostics). */
 int32_t xhe_set_stage_timing(xhe_ctx *ctx, int32_t level);
+
+/* Counters of the multiscalar check, summed over the verifications that finished on this context since the last reset (every part of
+ * a batch that xhe_verify_batch cut into parts counts as one verification): launches of the bucket accumulation kernel, its GPU time
+ * from a pair of HIP events around it on the stream it ran on, the sorted entries it went through (non-zero digits over all windows)
+ * and the terms with a non-zero scalar that entered the bucket sort (after terms that share a point were merged).  Collected only
+ * while enabled (two event records per verification).  No counterpart in the reference (measurement). */
+typedef struct xhe_msm_stats { uint64_t launches; uint64_t entries; uint64_t terms_nonzero; double accumulate_ms; } xhe_msm_stats;
+int32_t xhe_msm_stats_enable(xhe_ctx *ctx, int32_t on);
+int32_t xhe_msm_stats_read(xhe_ctx *ctx, xhe_msm_stats *out, int32_t reset);
 
 #ifdef __cplusplus
 }

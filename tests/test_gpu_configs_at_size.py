@@ -2,7 +2,7 @@
   * the mixed batch (groups of 16: multisig set-ups, one- and two-asset transfers, burns of both assets, co-signed
     transfers; /root/reference/src/lib.rs:492-703, shapes of /root/reference/benches/tx.rs:252-343) at 100 000
     transactions, and at 8 192 transactions against the oracle (verdict, every ledger byte, multisig_set_by, and a seeded
-    differential run over corrupted copies);
+    differential run over corrupted copies and over lying provers whose signatures hold);
   * the one-transfer batch at 125 000 transactions (a million transactions over eight GPUs).
 At full size the checks are properties that need no CPU verifier: accept, the ledger of the GPU's own apply path
 (Transaction::apply_without_verify, /root/reference/src/tx/verify.rs:545-619) and of the CPU apply path on a sample of
@@ -57,6 +57,37 @@ def _run(which, engine, oracle, sb, records, want_ledger=True):
     return (v.accept, v.err_code, v.first_bad_tx), (bytes(cts), list(ms)) if want_ledger else None
 
 
+def _resigned_mixed(lib, sb, secrets, tx, r, seed):
+    """Transaction tx of a mixed batch with one or two bits of its pre-image flipped behind the header fields (version, source,
+    fee, nonce stay), co-signed and signed again with the accounts' secrets: same length, valid signatures."""
+    import hashlib
+    rec = sb.records[sb.offsets[tx]:sb.offsets[tx + 1]]
+    g, pos = divmod(tx, 16)
+    n_items, n_ms = int.from_bytes(rec[2:4], "little"), int.from_bytes(rec[6:8], "little")
+    pre_off = 16 + (4 * n_items if rec[0] == codes.TX_TRANSFERS else 0)
+    pre_end = len(rec) - 65 * n_ms - 64
+    pre = bytearray(rec[pre_off:pre_end])
+    for _ in range(r.choice((1, 1, 2))):
+        pre[r.randrange(49, len(pre))] ^= 1 << r.randrange(8)
+    hdr = bytearray(rec[:pre_off]); hdr[1] = 0; hdr[6] = hdr[7] = 0
+    unsigned = bytes(hdr) + bytes(pre) + bytes(64)
+    secret = lambda a: secrets[32 * (6 * g + a):32 * (6 * g + a) + 32]
+    source = 2 + pos if pos < 2 else (2 + pos - 14 if pos >= 14 else 0)
+    ids, sigs = b"", b""
+    if n_ms:
+        h = (ctypes.c_uint8 * 32)()
+        if lib.xhe_tx_hash(unsigned, ctypes.c_uint64(len(unsigned)), h) != 0:
+            return None
+        for c in range(2):
+            sig = (ctypes.c_uint8 * 64)()
+            lib.xhe_sign(secret(4 + c), bytes(h), ctypes.c_uint64(32), hashlib.sha3_256(seed + b"/co%d" % c).digest(), sig)
+            ids += bytes([c]); sigs += bytes(sig)
+    out, n = (ctypes.c_uint8 * (len(rec) + 64))(), ctypes.c_uint64()
+    rc = lib.xhe_tx_finalize(unsigned, ctypes.c_uint64(len(unsigned)), 1 if n_ms else 0, n_ms, ids, sigs, secret(source), hashlib.sha3_256(seed).digest(), out,
+                             ctypes.c_uint64(len(out)), ctypes.byref(n))
+    return bytes(out)[:n.value] if rc == 0 else None
+
+
 @pytest.mark.timeout(900)
 def test_mixed_8192_against_the_oracle(engine, oracle):
     """8 192 mixed transactions (512 account groups): verdict, every ledger byte and multisig_set_by equal the oracle's; then
@@ -86,6 +117,29 @@ def test_mixed_8192_against_the_oracle(engine, oracle):
         seen[got[1]] = seen.get(got[1], 0) + 1
     print("verdict codes reached:", {codes.NAMES.get(k, k): v for k, v in seen.items()})
     assert len(seen) >= 4, seen
+    # 80 lying provers: one to two bits of a record's pre-image (keys, ciphertexts, sigma proofs, range proof, commitments)
+    # changed BEFORE its co-signers and its source sign it, so the signatures hold and the error comes from the proof stages
+    lib = _lib()
+    lib.xhe_synth_secrets.restype = ctypes.c_void_p
+    secrets = ctypes.string_at(lib.xhe_synth_secrets(sb.handle), 32 * 6 * (sb.n_txs // 16))
+    cases, unsignable = [], 0
+    for case in range(80):
+        tx = r.randrange(sb.n_txs)
+        rec = _resigned_mixed(lib, sb, secrets, tx, r, b"liar-%d" % case)
+        if rec is None:                               # a scalar made non-canonical: the builder does not sign a record that does not parse
+            unsignable += 1
+            continue
+        assert len(rec) == sb.offsets[tx + 1] - sb.offsets[tx]
+        cases.append((tx, sb.records[:sb.offsets[tx]] + rec + sb.records[sb.offsets[tx + 1]:]))
+    with ThreadPoolExecutor(16) as pool:
+        refs = list(pool.map(lambda c: _run("oracle", engine, oracle, sb, c[1], False)[0], cases))
+    seen = {}
+    for (tx, bad), ref in zip(cases, refs):
+        got = _run("gpu", engine, oracle, sb, bad, False)[0]
+        assert got == ref, (tx, got, ref)
+        seen[got[1]] = seen.get(got[1], 0) + 1
+    print("lying provers, verdict codes reached:", {codes.NAMES.get(k, k): v for k, v in seen.items()}, "unsignable:", unsignable)
+    assert len(seen) >= 3, seen
     sb.close()
 
 

@@ -97,7 +97,7 @@ def _rank(rank, world, port, records, ledger_blob, queue):
     try:
         ledger = pickle.loads(ledger_blob)
         txs = [Transaction(r) for r in records]
-        res = sharding.verify_batch_sharded(sharding.gpu_verify_fn(engine, seed="rank-%d" % rank), txs, ledger, dist)
+        res = sharding.verify_batch_sharded(sharding.gpu_verify_fn(engine, seed="rank-%d" % rank), txs, ledger, dist, apply_fn=sharding.gpu_apply_fn(engine))
         cts = {k.hex(): {a.hex(): c.hex() for a, c in acc.balances.items()} for k, acc in ledger.accounts.items()}
         ms = {k.hex(): (len(v[0]), v[1]) for k, v in ledger.multisig_accounts.items()}
         queue.put((rank, res, cts, ms, [len(s) for s in sharding.partition(records, world)]))
@@ -115,8 +115,11 @@ class _PublicKeyOnly:
 
 def _mixed_ledger_and_txs(n_groups, seed):
     """The mixed synthetic batch as Python objects: a Ledger mirror of its flat ledger and its records."""
+    return _ledger_and_txs(SyntheticBatch(16 * n_groups, seed=seed, mixed=True))
+
+
+def _ledger_and_txs(sb):
     from xelis_he_amd.api import Account, Ledger, Transaction
-    sb = SyntheticBatch(16 * n_groups, seed=seed, mixed=True)
     from test_gpu_fullsize import _RawView
     view = ctypes.cast(sb.view, ctypes.POINTER(_RawView)).contents      # the same struct with untyped pointers (c_char_p would stop at a NUL)
     keys = ctypes.string_at(view.account_keys, 32 * view.n_accounts)
@@ -158,8 +161,14 @@ def test_two_ranks_with_the_gpu_verifier():
     finally:
         engine.close()
     assert single_bad == (False, codes.ERR_SIGNATURE, 77)
+    _check_two_ranks(ledger, [([t.record for t in txs], (True, codes.OK, -1)), (bad, single_bad)], want_cts, want_ms, groups=True)
+    sb.close()
+
+
+def _check_two_ranks(ledger, cases, want_cts, want_ms, groups):
+    import pickle
     ctx = mp.get_context("spawn")
-    for records, expect in (([t.record for t in txs], (True, codes.OK, -1)), (bad, single_bad)):
+    for records, expect in cases:
         q, port = ctx.Queue(), _free_port()
         procs = [ctx.Process(target=_rank, args=(r, 2, port, records, pickle.dumps(ledger), q)) for r in range(2)]
         for p in procs:
@@ -170,7 +179,82 @@ def test_two_ranks_with_the_gpu_verifier():
             assert p.exitcode == 0
         for rank, res, cts, ms, sizes in out:
             assert res == expect, (rank, res)
-            assert all(s > 0 for s in sizes)
+            if groups:
+                assert all(s > 0 for s in sizes)
             if expect[0]:
                 assert cts == want_cts and ms == want_ms, rank
+
+
+def _plan(lib, sb, n_shards):
+    lib.xhe_plan_shards.restype = ctypes.c_int32
+    shard_of, ranges, bad = (ctypes.c_uint32 * sb.n_txs)(), ctypes.c_int32(), ctypes.c_int64()
+    assert lib.xhe_plan_shards(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), n_shards, shard_of, ctypes.byref(ranges), ctypes.byref(bad)) == 0
+    return list(shard_of), ranges.value
+
+
+@pytest.mark.timeout(900)
+def test_single_sender_chain_over_contexts(oracle):
+    """One sender for all 4 096 transactions (the reference bench's shape, /root/reference/benches/tx.rs:129-189): one account
+    group, so xhe_verify_batch_sharded cuts consecutive ranges, runs the ledger through them and verifies every range from the
+    state the ranges before it leave.  Two and three contexts against the single-context call and the oracle: verdict, failing
+    index, every ledger byte; for the valid chain, a bad signature in a later range, a missing transaction in the first range
+    and a transfer ciphertext that does not decode (the ledger chain breaks there)."""
+    import xelis_he_amd
+    e1, e2, e3 = xelis_he_amd.Engine(0), xelis_he_amd.Engine(0), xelis_he_amd.Engine(0)
+    try:
+        sb = SyntheticBatch(4096, n_transfers=1, n_senders=1, seed=b"one-sender", engine=e1)
+        shard_of, ranges = _plan(e1.lib, sb, 3)
+        assert ranges == 1 and shard_of == sorted(shard_of) and [shard_of.count(s) for s in range(3)] == [1366, 1365, 1365]
+        assert _plan(e1.lib, SyntheticBatch(512, n_transfers=1, n_senders=16, seed=b"groups"), 2)[1] == 0
+        want = _single(e1, sb, sb.records)
+        assert want[0] == (1, codes.OK, -1)
+        n_bal, n_acc = sb.view.contents.n_balances, sb.view.contents.n_accounts
+        ref_cts = (ctypes.c_uint8 * (64 * n_bal))()
+        ref_out, rv = LedgerOut(ref_cts, (ctypes.c_uint64 * n_acc)(), (ctypes.c_int64 * n_acc)()), Verdict()
+        oracle.xo_verify_batch(sb.records, sb.offsets, ctypes.c_uint64(sb.n_txs), sb.view, ctypes.byref(ref_out), ctypes.byref(rv), b"\x02" * 32)
+        assert (rv.accept, rv.err_code, rv.first_bad_tx) == want[0] and bytes(ref_cts) == want[1]
+        assert _sharded([e1, e2], sb, sb.records) == want
+        assert _sharded([e1, e2, e3], sb, sb.records) == want
+        offs = list(sb.offsets)
+        bad = bytearray(sb.records)
+        bad[offs[3001] - 40] ^= 1                         # transaction 3 000's signature: the last range of three, the second of two
+        undecodable = bytearray(sb.records)
+        c_at = offs[2000] + 16 + 4 + 49 + 64              # the amount commitment of transaction 2 000's transfer
+        undecodable[c_at:c_at + 32] = bytes([0xff]) * 32
+        for records, expect in ((bytes(bad), (0, codes.ERR_SIGNATURE, 3000)), (bytes(undecodable), (0, codes.ERR_DECOMPRESSION, 2000))):
+            assert _single(e1, sb, records)[0] == expect
+            assert _sharded([e1, e2], sb, records)[0] == expect
+            assert _sharded([e1, e2, e3], sb, records)[0] == expect
+        drop = 100
+        cut = offs[drop + 1] - offs[drop]
+        records = sb.records[:offs[drop]] + sb.records[offs[drop + 1]:]
+        new_offs = (ctypes.c_uint64 * sb.n_txs)(*(offs[:drop + 1] + [o - cut for o in offs[drop + 2:]]))
+        want_gap = _single(e1, sb, records, new_offs, sb.n_txs - 1)
+        assert want_gap[0] == (0, codes.ERR_GENERIC_PROOF, -1)
+        assert _sharded([e1, e2], sb, records, new_offs, sb.n_txs - 1)[0] == want_gap[0]
+        assert _sharded([e1, e2, e3], sb, records, new_offs, sb.n_txs - 1)[0] == want_gap[0]
+        sb.close()
+    finally:
+        for e in (e1, e2, e3):
+            e.close()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_single_sender_chain_with_the_gpu_verifier():
+    """The process-per-GPU driver on the single-sender chain: the ledger passes from rank 0 to rank 1 (a broadcast of the
+    ciphertexts, host tensors over gloo here), each rank verifies its range on the GPU."""
+    import xelis_he_amd
+    from xelis_he_amd.api import Transaction
+    engine = xelis_he_amd.Engine(0)
+    try:
+        sb = SyntheticBatch(512, n_transfers=2, n_senders=1, seed=b"ranks-one-sender", engine=engine)
+        _, ledger, txs = _ledger_and_txs(sb)
+        single = ledger.clone()
+        Transaction.verify_batch(engine, txs, single, seed="single")
+        want_cts = {k.hex(): {a.hex(): c.hex() for a, c in acc.balances.items()} for k, acc in single.accounts.items()}
+    finally:
+        engine.close()
+    bad = [t.record for t in txs]
+    bad[400] = bad[400][:-20] + bytes([bad[400][-20] ^ 1]) + bad[400][-19:]
+    _check_two_ranks(ledger, [([t.record for t in txs], (True, codes.OK, -1)), (bad, (False, codes.ERR_SIGNATURE, 400))], want_cts, {}, groups=False)
     sb.close()

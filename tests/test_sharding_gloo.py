@@ -38,13 +38,38 @@ def _oracle_verify_fn():
     return run
 
 
+def _oracle_apply_fn():
+    """Transaction::apply_without_verify over a range with the oracle: the ledger's ciphertexts after the range, or None."""
+    import helpers
+    from xelis_he_amd.api import LedgerOut
+    oracle = helpers.load_oracle()
+    oracle.xo_apply_batch.restype = ctypes.c_int32
+
+    def run(range_txs, ledger, start_cts):
+        start = ledger.clone()
+        f = start.flatten()
+        for i, (acc_i, asset) in enumerate(f["slots"]):
+            start.accounts[f["keys"][acc_i]].balances[asset] = start_cts[64 * i:64 * i + 64]
+        f = start.flatten()
+        blob = b"".join(t.record for t in range_txs)
+        offs = [0]
+        for t in range_txs:
+            offs.append(offs[-1] + len(t.record))
+        offsets = (ctypes.c_uint64 * len(offs))(*offs)
+        cts = (ctypes.c_uint8 * max(64 * len(f["slots"]), 1))()
+        out = LedgerOut(cts, (ctypes.c_uint64 * max(len(f["keys"]), 1))(), (ctypes.c_int64 * max(len(f["keys"]), 1))())
+        rc = oracle.xo_apply_batch(blob, offsets, ctypes.c_uint64(len(range_txs)), ctypes.byref(f["view"]), ctypes.byref(out))
+        return bytes(cts)[:64 * len(f["slots"])] if rc == 0 else None
+    return run
+
+
 def _worker(rank, world, port, records, ledger, queue):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         txs = [Transaction(r) for r in records]
-        res = sharding.verify_batch_sharded(_oracle_verify_fn(), txs, ledger, dist)
+        res = sharding.verify_batch_sharded(_oracle_verify_fn(), txs, ledger, dist, apply_fn=_oracle_apply_fn())
         cts = {k.hex(): {a.hex(): c.hex() for a, c in acc.balances.items()} for k, acc in ledger.accounts.items()}
         queue.put((rank, res, cts, sharding.partition(records, world)))
     finally:
@@ -141,4 +166,32 @@ def test_two_ranks_first_error_wins(oracle):
     single = oracle_verify_batch(oracle, [Transaction(r) for r in gap2], ledger.clone())
     assert single == (False, codes.ERR_GENERIC_PROOF, -1)
     for rank, res, _, _ in _run_two_ranks(gap2, ledger):
+        assert res == single
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_single_sender_chain(oracle):
+    """One sender for every transaction (the reference bench's shape, benches/tx.rs:129-189): a single account group, so the
+    batch is cut into consecutive ranges and the ledger passes from rank 0 to rank 1.  Verdict and ledger equal the
+    single-process run for a valid chain, a bad signature in the second range, and a gap in the first range."""
+    ledger, txs = _chains(1, 6, "one")
+    recs = [t.record for t in txs]
+    shards, ranges = sharding.plan(recs, 2)
+    assert ranges and shards == [[0, 1, 2], [3, 4, 5]]
+    assert sharding.plan([t.record for t in _chains(2, 3, "two")[1]], 2)[1] is False          # two equal groups: no ranges
+    single = ledger.clone()
+    assert oracle_verify_batch(oracle, txs, single) == (True, codes.OK, -1)
+    want = {k.hex(): {a.hex(): c.hex() for a, c in acc.balances.items()} for k, acc in single.accounts.items()}
+    for rank, res, cts, _ in _run_two_ranks(recs, ledger):
+        assert res == (True, codes.OK, -1)
+        assert cts == want
+    bad = list(recs)
+    bad[4] = bad[4][:-64] + bytes(64)
+    assert oracle_verify_batch(oracle, [Transaction(r) for r in bad], ledger.clone()) == (False, codes.ERR_SIGNATURE, 4)
+    for rank, res, _, _ in _run_two_ranks(bad, ledger):
+        assert res == (False, codes.ERR_SIGNATURE, 4)
+    gap = recs[:1] + recs[2:]                      # the second link is missing: every later proof is against a balance never reached
+    single = oracle_verify_batch(oracle, [Transaction(r) for r in gap], ledger.clone())
+    assert single == (False, codes.ERR_GENERIC_PROOF, -1)
+    for rank, res, _, _ in _run_two_ranks(gap, ledger):
         assert res == single

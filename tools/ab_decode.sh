@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { name=$1; shift; env "$@" timeout -k 10 300 python -u bench.py --steps 20 --warmup 3 --e2e-reps 0 --cpu-sample 0 > gpurun_out/ab_$name.log 2>&1 || exit 1; python -c "
+run() { name=$1; shift; env "$@" timeout -k 10 300 python -u bench.py --steps 20 --warmup 3 --lean --value-basis resident > gpurun_out/ab_$name.log 2>&1 || exit 1; python -c "
 import json,sys
 d=json.loads(open('gpurun_out/ab_$name.log').read().strip().splitlines()[-1]); print('$name', d['ms_per_step'], d['stages_ms'], 'secondary', d['secondary']['ms_per_step'])"; }
 run occ2_512 XHE_DECODE_OCC=2

@@ -5,7 +5,7 @@ name=$1; shift
 for rep in 1 2; do
   for v in "$@"; do
     env_arg="$name=$v"
-    env $env_arg timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 0 --steps 30 --warmup 5 > gpurun_out/ab_env.json 2> gpurun_out/ab_env.err || { tail -3 gpurun_out/ab_env.err; exit 1; }
+    env $env_arg timeout -k 10 300 python -u bench.py --lean --value-basis resident --steps 30 --warmup 5 > gpurun_out/ab_env.json 2> gpurun_out/ab_env.err || { tail -3 gpurun_out/ab_env.err; exit 1; }
     python - "$env_arg" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_env.json"))

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
   for spec in "$@"; do
     v=${spec%%:*}; e=""; [ "$spec" != "$v" ] && e=${spec#*:}
-    env XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" $e timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 0 --steps 30 --warmup 5 > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err || { tail -3 gpurun_out/ab_lib.err; exit 1; }
+    env XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" $e timeout -k 10 300 python -u bench.py --lean --value-basis resident --steps 30 --warmup 5 > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err || { tail -3 gpurun_out/ab_lib.err; exit 1; }
     python - "$spec" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_lib.json"))

@@ -3,12 +3,12 @@
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
   for v in "$@"; do
-    XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 2 --steps 5 --warmup 2 > gpurun_out/ab_pipe.json 2> gpurun_out/ab_pipe.err || { tail -3 gpurun_out/ab_pipe.err; exit 1; }
+    XHE_LIBRARY="$GRAFT_REPO_ROOT/tools/variants/libxhe_$v.so" timeout -k 10 300 python -u bench.py --cpu-sample 0 --no-secondary --resident-steps 0 --steps 10 --warmup 3 > gpurun_out/ab_pipe.json 2> gpurun_out/ab_pipe.err || { tail -3 gpurun_out/ab_pipe.err; exit 1; }
     python - "$v" "$rep" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_pipe.json"))
-e = d["end_to_end"]
-print("variant", sys.argv[1], "rep", sys.argv[2], "single", e["ms_per_batch"], "pipelined", e["pipelined"]["ms_per_batch"], "steady", e["pipelined"]["steady_ms_per_batch"], flush=True)
+e = d["pipelined"]
+print("variant", sys.argv[1], "rep", sys.argv[2], "single", d["ms_per_step"], "pipelined", e["ms_per_batch"], "steady", e["steady_ms_per_batch"], flush=True)
 PY
   done
 done

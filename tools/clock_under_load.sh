@@ -1,7 +1,7 @@
 #!/bin/bash
 # Samples the GPU's shader clock and power (rocm-smi) while the headline verification runs in a loop.
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 200 python -u bench.py --cpu-sample 0 --no-secondary --e2e-reps 0 --steps 600 --warmup 5 > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
+timeout -k 10 200 python -u bench.py --lean --value-basis resident --steps 600 --warmup 5 > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
 pid=$!
 sleep 40
 for i in 1 2 3 4 5 6; do

@@ -13,7 +13,8 @@ n, t = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 lib = _lib()
 eng = xelis_he_amd.Engine(0)
-batch = SyntheticBatch(n, t, min(1024, n), seed=b"e2e", threads=16, engine=eng)
+mixed = os.environ.get("XHE_EXP_MIXED") == "1"           # the mixed batch (groups of 16) instead of transfers
+batch = SyntheticBatch(n - n % 16 if mixed else n, t, min(1024, n), seed=b"e2e", threads=16, engine=eng, mixed=mixed)
 v = Verdict()
 settings = sys.argv[4].split(",") if len(sys.argv) > 4 else [None]
 for parts in settings:

@@ -150,7 +150,7 @@ struct xhe_ctx {
     hipStream_t stream = nullptr;                 // main stream: transcript, proof scalars, multiscalar check, verdict
     hipStream_t side[3] = {nullptr, nullptr, nullptr};            // [0] ledger scan + static-generator scalars, [1] point decoding (+ signatures), [2] signatures of
                                                                   // large batches only; all at the default priority
-    hipEvent_t ev_keys = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_keys = nullptr, ev_static_done = nullptr, ev_setup = nullptr, ev_scalars = nullptr, ev_points_checked = nullptr, ev_early = nullptr, ev_side_done[3] = {nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;            // host-to-device copies of the uploads only (no kernels): an upload may run beside a verification
     hipEvent_t ev_stage_free = nullptr;           // fires when the last copy out of the pinned staging memory has finished
     std::string error; std::mutex err_mu;
@@ -169,6 +169,7 @@ struct xhe_ctx {
     // level-0 workspace
     dev_buf in_bytes, scalars, niels, ok, result, xyzt;
     msm_workspace msm;
+    msm_workspace msm_odd;      // the bucket workspace of every second part of a batch verified in parts (see batch_verify_enqueue, `lane`)
     // constant tables
     dev_buf base_pts;          // B, H as affine Niels
     dev_buf gtab, htab;        // fixed-base tables: 8 x 256 multiples of G, 32 x 256 multiples of H
@@ -178,6 +179,7 @@ struct xhe_ctx {
     u32 gen_tab_cap = 0;       // the capacity gen_tab was built for, 0 = none
     bool tables_ready = false;
     unsigned char *static_scratch = nullptr;   // this device's copy of `scratch`
+    bool stats_on = false; xhe_msm_stats stats{0, 0, 0, 0.0};      // xhe_msm_stats_enable / xhe_msm_stats_read
 };
 
 

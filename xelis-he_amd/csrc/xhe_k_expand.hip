@@ -135,6 +135,21 @@ __global__ void __launch_bounds__(128) k_expand_descriptors(expand_args a) {
     }
     a.out_txs[i] = d;
     a.tx_err[i] = key; a.apply_err[i] = akey;
+    // Scalar::from_canonical_bytes of the reference's deserialisation: the proofs' responses, the signatures, the range proof's
+    // t_x, t_x_blinding, e_blinding and a, b (the same list as record_scalars_canonical on the host)
+    {
+        bool canonical = true;
+        auto check = [&](u64 off, u32 count) {
+            for (u32 s = 0; s < count; s++) { u32 w[8]; load_words_unaligned(w, a.bytes + off + 32ull * s); canonical = canonical && sc_words_canonical(w); }
+        };
+        for (u32 k = 0; k < T; k++) check(rec + xf[k].off + xf[k].len - 64, 2);
+        for (u32 k = 0; k < A; k++) check(rec + t.cm_off + 256ull * k + 160, 3);
+        check(rec + t.sig_off, 2);
+        for (u32 k = 0; k < t.n_multisig; k++) check(rec + t.ms_off + 65ull * k + 1, 2);
+        check(rec + t.rp_off + 128, 3);
+        check(rec + t.rp_off + 224 + 64ull * lg, 2);
+        if (!canonical) atomicMin(a.noncanonical_first, i);
+    }
 }
 
 // the points shared between transactions (behind the transactions' blocks in decs[] and in the two decode lists they belong to)

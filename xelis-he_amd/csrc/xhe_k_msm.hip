@@ -136,14 +136,22 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32
 }
 
 // digits[w * n + i]: bit 15 = sign, bits 0..14 = magnitude (0 = no contribution)
-__global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits, u32 *__restrict__ big_count) {
+// nonzero_count (zero before the launch) receives the number of terms whose scalar is not zero: what the accumulation really works on
+// once terms that share a point have been merged into one
+__global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits, u32 *__restrict__ big_count,
+                                                    u32 *__restrict__ nonzero_count) {
     wave_priority_high();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) big_count[0] = 0;                       // the merge stage's list of oversized buckets starts empty
-    if (i >= n) return;
     u32 s[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
+    for (int k = 0; k < 8; k++) s[k] = i < n ? scalars[8 * i + k] : 0u;
+    {
+        const bool nonzero = (s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) != 0;
+        const unsigned long long mask = __ballot(nonzero);
+        if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nonzero_count, (u32)__popcll(mask));
+    }
+    if (i >= n) return;
     msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
         u32 a = d < 0 ? (u32)(-d) : (u32)d;
         digits[(u64)w * n + i] = (unsigned short)(a | (d < 0 ? 0x8000u : 0u));
@@ -663,8 +671,9 @@ __global__ void __launch_bounds__(64) k_msm_reduce_windows(const u32 *__restrict
 // Horner over the windows, most significant first.  The 252 doublings are one dependent chain, so the whole
 // wavefront shares the point (xhe_wide.h: a lane per limb): a doubling is two ten-step products.
 // Writes the identity flag and, when out_words is not null, the compressed result.
+// out_flag[1] receives the number of sorted entries (non-zero digits over all windows) the accumulation went through.
 __global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, msm_plan p, const u32 *__restrict__ extra_point /*may be null*/,
-                                                   u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag) {
+                                                   u32 *__restrict__ out_words /*8, may be null*/, u32 *__restrict__ out_flag, const u32 *__restrict__ entries_total) {
     wave_priority_high();
     const wd_lane L = wd_lane_init();
     wd_point R = wd_load(win + 32ull * (p.W - 1), L);
@@ -681,7 +690,7 @@ __global__ void __launch_bounds__(64) k_msm_horner(const u32 *__restrict__ win, 
         u32 enc[8]; ristretto_encode_words(enc, full);
         if (threadIdx.x == 0) for (int i = 0; i < 8; i++) out_words[i] = enc[i];
     }
-    if (threadIdx.x == 0) out_flag[0] = ident ? 1u : 0u;
+    if (threadIdx.x == 0) { out_flag[0] = ident ? 1u : 0u; out_flag[1] = entries_total[0]; }
 }
 
 // ---- fixed points: table look-ups instead of buckets ---------------------------------------------------
@@ -759,7 +768,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     const u32 tiles = (u32)msm_sort_tiles(n, p), lds_bytes = p.B * 4;
     unsigned short *digits = (unsigned short *)ws.digits;
     MARK("msm_histogram");
-    hipLaunchKernelGGL(k_msm_digits, dim3(n ? grid_for(n, 256) : 1), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list);
+    hipLaunchKernelGGL(k_msm_digits, dim3(n ? grid_for(n, 256) : 1), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list, d_result + 10);
     if (!p.fine_bits) {
         hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
         hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);
@@ -797,7 +806,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     hipLaunchKernelGGL(k_msm_reduce_windows, dim3(p.W), dim3(64), 0, st, ws.segs, p, ws.wins);
     MARK("msm_horner");
     if (deps.extra_ready && (e = hipStreamWaitEvent(st, deps.extra_ready, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins, p, deps.extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8);
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, ws.wins, p, deps.extra_point, want_encoding ? d_result : (u32 *)nullptr, d_result + 8, ws.offsets + n_buckets);
 #undef MARK
     return hipGetLastError();
 }

@@ -143,9 +143,11 @@ __global__ void __launch_bounds__(256) k_point_errors(const dev_tx *__restrict__
     if (rp_bad) rp_err[i] = 1;
 }
 // out[0..1]: (first failing tx << 32 | key) as u64 min; out[2]: first tx with a range-proof failure
+// out[3]: first transaction with a scalar that is not canonical (found when the batch was uploaded), or 0xffffffff
 __global__ void __launch_bounds__(256) k_verdict(const u32 *__restrict__ tx_err, const u32 *__restrict__ rp_err, u32 n_txs, unsigned long long *__restrict__ first_err,
-                                                 u32 *__restrict__ first_rp) {
+                                                 u32 *__restrict__ first_rp, const u32 *__restrict__ noncanonical_first) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) first_rp[1] = noncanonical_first[0];
     if (i >= n_txs) return;
     u32 k = tx_err[i];
     if (k != ERRKEY_NONE) atomicMin(first_err, ((unsigned long long)i << 32) | k);
@@ -192,8 +194,8 @@ void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, co
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err) {
     if (n_txs) hipLaunchKernelGGL(k_point_errors, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, txs, cms, xfers, n_txs, ok, tx_err, rp_err);
 }
-void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp) {
-    if (n_txs) hipLaunchKernelGGL(k_verdict, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, tx_err, rp_err, n_txs, first_err, first_rp);
+void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp, const u32 *noncanonical_first) {
+    if (n_txs) hipLaunchKernelGGL(k_verdict, dim3(grid_for(n_txs, 256)), dim3(256), 0, st, tx_err, rp_err, n_txs, first_err, first_rp, noncanonical_first);
 }
 
 }  // namespace xhe

@@ -25,7 +25,8 @@ struct msm_ws {
 struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chunk_sums, big_list, segs, wins, tmp, coarse; };
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
-// result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8)
+// result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8); d_result[9] = sorted
+// entries the accumulation went through, d_result[10] += terms with a non-zero scalar (the caller clears d_result before the launch)
 // What the multiscalar multiplication waits for on other streams: the sort of the scalars needs none of it.
 struct msm_deps {
     hipEvent_t points_ready[2] = {nullptr, nullptr};   // waited for before the first point is gathered
@@ -63,7 +64,8 @@ void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases
 // list: the entries to decode, or null for the bulk pass (everything but the ledger scan's inputs and, unless bulk_takes_keys, the public keys)
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background = false);
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
-void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp);
+// first_rp[1] receives *noncanonical_first (the upload's range check of the scalars, k_expand_descriptors)
+void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp, const u32 *noncanonical_first);
 // transcript, hashes, signatures
 // tmpl/segs: transcript templates and per-transaction segment tables; list/tiles: the transactions with a template, sorted by
 // template and padded to whole tiles; the stream buffer (plan.stream_words 8-byte words) is reused by the passes;

@@ -33,8 +33,10 @@ static __device__ __align__(256) unsigned char scratch[MSM_STATIC_BYTES];
 static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory per context, at most
 // xhe_verify_batch cuts a batch whose records reach twice this size into parts of about this size, at most SPLIT_PARTS_MAX
 // (verify_batch_split below).  Measured on 100 000 transactions of 8 transfers (390 MB): one piece 39-41 ms, 4 parts 31 ms,
-// 6 parts 28-29 ms, 8 parts 30 ms, 12 parts 33 ms -- every part adds fixed host work to the one uploader thread.
-static constexpr u64 SPLIT_PART_BYTES = 64ull << 20;
+// 6 parts 27-28 ms, 8 parts 28 ms, 10 parts 31 ms -- every part adds fixed host work to the one uploader thread and a latency-bound
+// head and tail on the device; batches of one-transfer transactions (125 000: 178 MB) want parts of their own size class, hence
+// the part size below rather than a sixth of the largest shape.
+static constexpr u64 SPLIT_PART_BYTES = 40ull << 20;
 static constexpr u64 SPLIT_PARTS_MAX = 6;
 static constexpr u32 VERDICT_SLOTS = 4;              // verifications whose verdict words may be on their way to the host at once
 // From this batch size on the signatures get a stream of their own and start beside the transcripts (measured on the
@@ -54,22 +56,27 @@ struct xhe_batch {
     dev_buf thread_excl, block_tot, slot_base, slot_final, emit_incl, final_cts, verdict, seed;
     dev_buf static_partials, static_sum;       // the static generators' contribution to the multiscalar check (from the fixed-base tables)
     dev_buf slot_of_used;                      // used slot -> index of its balance in the ledger view
+    dev_buf noncanonical;                      // index of the first transaction with a scalar that is not below the group order (the upload's device check), else 0xffffffff
     dev_buf arena_up, arena_ws, arena_bytes;   // the blocks every buffer above is a range of: uploaded tables, workspace, the byte buffer
     std::vector<u32> group_off;   // per lg: offset into group_txs
     hipEvent_t ev_uploaded = nullptr;   // fires on the copy stream when every table of the batch has arrived
     hipEvent_t ev_done = nullptr;       // fires on the main stream when a verification's verdict words have been read back
     hipEvent_t ev_carried = nullptr;    // fires on side stream 0 when the batch's resulting ciphertexts have been handed on (batches verified in parts)
+    hipEvent_t ev_acc[2] = {nullptr, nullptr};   // around the bucket accumulation kernel of the verification in flight (xhe_msm_stats)
+    bool acc_timed = false;
     u32 *verdict_words = nullptr;       // where in the context's pinned memory the verdict words of the verification in flight arrive
     bool in_flight = false;             // a verification has been enqueued and not yet finished
+    u32 lane = 0;                       // ... on which pair of streams (batch_verify_enqueue)
+    hipStream_t main_stream = nullptr, ledger_stream = nullptr;      // that verification's main stream, and the one its ledger scan ran on
     bool trivial = false;               // ... of an empty batch
     std::shared_lock<std::shared_mutex> tables_lock;     // held from a verification's first launch to its finish: its kernels read the context's tables
     bool verified_ok = false;
     void release() {
         for (dev_buf *b : {&static_partials, &static_sum, &slot_of_used}) b->release();
-        for (hipEvent_t *e : {&ev_done, &ev_carried}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        for (hipEvent_t *e : {&ev_done, &ev_carried, &ev_acc[0], &ev_acc[1]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         for (dev_buf *b : {&ex_txs, &ex_xfs, &ex_cms, &ex_mss, &sh_decs, &sh_early, &sh_key, &ex_slot_pos, &ex_slot_base, &merge_pairs, &key_terms, &key_group_off, &bytes, &txs, &cms, &xfers, &decs, &early_decs, &key_decs, &bulk_decs, &sig_keys, &sig_tab, &ops, &sigs, &tx_err0, &apply_err0, &slot_last_op, &emit_slot, &ms_hash_tx, &group_txs, &tmpl, &segs, &serial_txs, &tr_list, &tr_tiles, &tr_stream, &sig_state, &sig_r, &pts, &ok, &chal,
                            &scalars, &term_point, &gh, &gh_sums, &rp_ctx, &rp_acc, &rp_mat, &rp_dig, &rp_bins, &rp_rho, &tx_err, &rp_err, &ms_hash, &thread_excl, &block_tot, &slot_base,
-                           &slot_final, &emit_incl, &final_cts, &verdict, &seed, &arena_up, &arena_ws, &arena_bytes})
+                           &slot_final, &emit_incl, &final_cts, &verdict, &seed, &noncanonical, &arena_up, &arena_ws, &arena_bytes})
             b->release();
         if (ev_uploaded) { (void)hipEventDestroy(ev_uploaded); ev_uploaded = nullptr; }
     }
@@ -79,11 +86,23 @@ void xhe::set_error(xhe_ctx *ctx, const std::string &msg) { if (ctx) { std::lock
 
 // MSM over device-resident canonical scalars and affine-Niels records; result (8 words encoding, flag)
 // into d_result[0..8], d_result[8].
-static hipError_t timer_mark(void *user, const char *name) { xhe_ctx *ctx = (xhe_ctx *)user; return ctx->timer.mark(name, ctx->stream); }
+struct msm_mark_target { xhe_ctx *ctx; hipStream_t stream; bool timing; hipEvent_t *acc_events; };
+static hipError_t timer_mark(void *user, const char *name) {
+    msm_mark_target *t = (msm_mark_target *)user;
+    // the pair of events around the bucket accumulation kernel (xhe_msm_stats): "msm_merge" is the stage behind it
+    if (t->acc_events) {
+        hipError_t e = !strcmp(name, "msm_accumulate") ? hipEventRecord(t->acc_events[0], t->stream) : !strcmp(name, "msm_merge") ? hipEventRecord(t->acc_events[1], t->stream) : hipSuccess;
+        if (e != hipSuccess) return e;
+    }
+    return t->timing ? t->ctx->timer.mark(name, t->stream) : hipSuccess;
+}
 
+// lane 1: on the stream and in the workspace of every second part of a batch verified in parts (batch_verify_enqueue)
 static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, u32 *d_result, bool want_encoding,
-                          bool timing, const msm_deps &deps = msm_deps()) {
-    msm_workspace &ws = ctx->msm;
+                          bool timing, const msm_deps &deps = msm_deps(), hipStream_t stream = nullptr, u32 lane = 0, hipEvent_t *acc_events = nullptr) {
+    msm_workspace &ws = lane ? ctx->msm_odd : ctx->msm;
+    if (!stream) stream = ctx->stream;
+    msm_mark_target target{ctx, stream, timing, acc_events};
     msm_plan p = msm_make_plan(n);
     if (n * p.W > 0xfffffff0ull) { set_error(ctx, "multiscalar multiplication too large for 32-bit positions"); return XHE_E_ARG; }
     msm_ws_bytes need = msm_workspace_bytes(n, p);
@@ -101,7 +120,7 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.coarse.reserve(need.coarse));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.tile_hist.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), ws.digits.as<u32>(), ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>(), ws.tmp.as<u32>(), ws.coarse.as<u32>()};
-    HIPCHK(ctx, msm_launch(ctx->stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, timing ? timer_mark : nullptr, ctx));
+    HIPCHK(ctx, msm_launch(stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, (timing || acc_events) ? timer_mark : nullptr, &target));
     return 0;
 }
 
@@ -154,7 +173,8 @@ int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
 
 static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]);
 static constexpr int32_t ENQUEUE_TABLES_BUSY = 2;
-static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side, bool may_block = true);
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side, bool may_block = true, int lane_or_none = -1,
+                                    u32 *carry_ledger = nullptr);
 static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict);
 
 extern "C" {
@@ -173,7 +193,7 @@ xhe_ctx *xhe_create(int device_id) {
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side[0]) == hipSuccess && hipStreamCreate(&ctx->side[1]) == hipSuccess && hipStreamCreate(&ctx->side[2]) == hipSuccess &&
               hipStreamCreate(&ctx->copy_stream) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->ev_stage_free, hipEventDisableTiming) == hipSuccess && hipEventRecord(ctx->ev_stage_free, ctx->copy_stream) == hipSuccess;
-    for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
+    for (hipEvent_t *e : {&ctx->ev_keys, &ctx->ev_static_done, &ctx->ev_setup, &ctx->ev_scalars, &ctx->ev_points_checked, &ctx->ev_early, &ctx->ev_side_done[0], &ctx->ev_side_done[1], &ctx->ev_side_done[2]})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->verdict_host, 64 * VERDICT_SLOTS, hipHostMallocDefault) == hipSuccess;
     // the address of this device's copy of the static scratch array (the array's name itself is a host-side stand-in)
@@ -187,14 +207,16 @@ void xhe_destroy(xhe_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->copy_stream}) if (s) (void)hipStreamSynchronize(s);
     for (dev_buf *b : {&ctx->in_bytes, &ctx->scalars, &ctx->niels, &ctx->ok, &ctx->result, &ctx->xyzt, &ctx->msm.hist, &ctx->msm.offsets, &ctx->msm.tile_hist, &ctx->msm.digits,
-                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab})
+                       &ctx->msm.sorted, &ctx->msm.buckets, &ctx->msm.chunk_sums, &ctx->msm.big_list, &ctx->msm.segs, &ctx->msm.wins, &ctx->msm.tmp, &ctx->msm.coarse,
+                       &ctx->msm_odd.hist, &ctx->msm_odd.offsets, &ctx->msm_odd.tile_hist, &ctx->msm_odd.digits, &ctx->msm_odd.sorted, &ctx->msm_odd.buckets, &ctx->msm_odd.chunk_sums, &ctx->msm_odd.big_list,
+                       &ctx->msm_odd.segs, &ctx->msm_odd.wins, &ctx->msm_odd.tmp, &ctx->msm_odd.coarse, &ctx->base_pts, &ctx->gtab, &ctx->htab, &ctx->static_pts, &ctx->gen_tab})
         b->release();
     ctx->pool.drain();
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->verdict_host) (void)hipHostFree(ctx->verdict_host);
     for (u8 *p : ctx->readback) if (p) (void)hipHostFree(p);
     ctx->timer.release();
-    for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_keys, ctx->ev_static_done, ctx->ev_setup, ctx->ev_scalars, ctx->ev_points_checked, ctx->ev_early, ctx->ev_side_done[0], ctx->ev_side_done[1], ctx->ev_side_done[2]}) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_stage_free) (void)hipEventDestroy(ctx->ev_stage_free);
     for (hipStream_t s : {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2], ctx->copy_stream}) if (s) (void)hipStreamDestroy(s);
     delete ctx;
@@ -205,6 +227,18 @@ const char *xhe_last_error(const xhe_ctx *ctx) { return ctx ? ctx->error.c_str()
 int32_t xhe_set_stage_timing(xhe_ctx *ctx, int32_t level) {
     if (!ctx || level < 0 || level > 2) return XHE_E_ARG;
     ctx->timer.level = level;
+    return 0;
+}
+
+int32_t xhe_msm_stats_enable(xhe_ctx *ctx, int32_t on) {
+    if (!ctx) return XHE_E_ARG;
+    ctx->stats_on = on != 0;
+    return 0;
+}
+int32_t xhe_msm_stats_read(xhe_ctx *ctx, xhe_msm_stats *out, int32_t reset) {
+    if (!ctx || !out) return XHE_E_ARG;
+    *out = ctx->stats;
+    if (reset) ctx->stats = xhe_msm_stats{0, 0, 0, 0.0};
     return 0;
 }
 
@@ -368,7 +402,7 @@ static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threa
 // (1: always the matrix path; a huge value: never); it is read when a batch is uploaded and kept with the batch.
 static u64 rp_gemm_min_rows() { const char *e = getenv("XHE_RP_GEMM_MIN_ROWS"); return e ? strtoull(e, nullptr, 10) : 512ull; }
 static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
-                                 xhe_verdict *structural, bool wait_for_copies) {
+                                 xhe_verdict *structural, bool wait_for_copies, const ledger_index *shared_index = nullptr) {
     if (!ctx || !offsets || !in || !batch_out || (n_txs && !records)) return XHE_E_ARG;
     if (n_txs > 0x7ffffff0ull) return XHE_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -424,7 +458,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     }
     auto join_copier = [&]() { if (copier.joinable()) copier.join(); };
     if (!ctx->workers.size() && host_threads > 1) ctx->workers.start(host_threads - 1);
-    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in, &ctx->workers, &ctx->arena);
+    bool parsed = ingest_batch(hb, records, offsets, n_txs, *in, &ctx->workers, &ctx->arena, shared_index);
     lap("ingest");
     join_copier();
     lap("byte buffer staged and enqueued");
@@ -506,7 +540,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
             else worst = std::max<u64>(worst, rp_matrix_part_rows(rows, lg) * (72ull << lg));
         }
         RS(rp_mat, worst); RS(rp_dig, dig); RS(rp_bins, bins); RS(rp_rho, 36ull * RP_GEMM_RHO_PARTS);
-        RS(static_partials, ((2ull + 2ull * GEN_TABLE_CAP_MAX) * 32 / 256 + 2) * 128); RS(static_sum, 128);
+        RS(static_partials, ((2ull + 2ull * GEN_TABLE_CAP_MAX) * 32 / 256 + 2) * 128); RS(static_sum, 128); RS(noncanonical, 64);
     }
 #undef RS
     auto fail = [&](const char *what, hipError_t e) { set_error(ctx, std::string(what) + ": " + hipGetErrorString(e)); xhe_batch_free(ctx, B); *batch_out = nullptr; return XHE_E_HIP; };
@@ -558,6 +592,8 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
         ea.n_shared = (u32)hb.shared_decs.size(); ea.n_shared_early = (u32)hb.shared_early.size(); ea.n_shared_key = (u32)hb.shared_key.size(); ea.n_slots = (u32)hb.slot_pos.size();
         ea.blk_end = hb.blk_end; ea.early_end = hb.early_end; ea.key_end = hb.key_end;
         ea.slot_last_op = B->slot_last_op.as<u32>();
+        ea.bytes = B->bytes.as<u8>(); ea.noncanonical_first = B->noncanonical.as<u32>();
+        HIPCHK(ctx, hipMemsetAsync(B->noncanonical.p, 0xff, 64, st));
         launch_expand(st, ea);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -569,7 +605,17 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
 }
 int32_t xhe_batch_upload(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
                          xhe_verdict *structural) {
-    return batch_upload_impl(ctx, records, offsets, n_txs, in, batch_out, structural, true);
+    int32_t rc = batch_upload_impl(ctx, records, offsets, n_txs, in, batch_out, structural, true);
+    if (rc != 0 || !*batch_out) return rc;
+    // the device's range check of the scalars has run by now (the upload waited for its copies and kernels): a batch with a
+    // scalar that is not canonical is malformed like one whose lengths are wrong
+    xhe_batch *B = *batch_out;
+    if (B->hb.structural.accept && B->noncanonical.p) {
+        u32 first = 0xffffffffu;
+        HIPCHK(ctx, hipMemcpy(&first, B->noncanonical.p, 4, hipMemcpyDeviceToHost));
+        if (first != 0xffffffffu) { B->hb.structural = {0, XHE_ERR_MALFORMED, (int64_t)first}; if (structural) *structural = B->hb.structural; }
+    }
+    return rc;
 }
 
 int32_t xhe_batch_verify(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t rng_seed[32]) {
@@ -622,7 +668,7 @@ int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
         HIPCHK(ctx, tm.mark("verdict", st));
         // only the ciphertexts were decoded: every other point still carries its initial "valid" mark
         launch_point_errors(st, B->txs.as<dev_tx>(), B->cms.as<dev_cm>(), B->xfers.as<dev_xfer>(), n_txs, ok, B->tx_err.as<u32>(), B->rp_err.as<u32>());
-        launch_verdict(st, B->tx_err.as<u32>(), B->rp_err.as<u32>(), n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
+        launch_verdict(st, B->tx_err.as<u32>(), B->rp_err.as<u32>(), n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2, B->noncanonical.as<u32>());
     }
     HIPCHK(ctx, tm.mark("end", st));
     HIPCHK(ctx, hipGetLastError());
@@ -631,6 +677,7 @@ int32_t xhe_batch_apply(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
     HIPCHK(ctx, hipStreamSynchronize(st));
     tm.finish();
     u64 first_err = (u64)host[0] | ((u64)host[1] << 32);
+    if (n_txs && host[3] != 0xffffffffu) { *verdict = {0, XHE_ERR_MALFORMED, (int64_t)host[3]}; return 0; }      // a scalar that is not canonical: the record would not have deserialised
     if (first_err != ~0ull) { *verdict = {0, (int32_t)(first_err & 0xff), (int64_t)(first_err >> 32)}; return 0; }
     *verdict = {1, XHE_OK, -1};
     B->verified_ok = true;
@@ -652,6 +699,19 @@ int32_t xhe_batch_read_ledger(xhe_ctx *ctx, xhe_batch *B, const xhe_ledger_out *
     }
     if (out->account_nonces) memcpy(out->account_nonces, B->in_nonces.data(), 8 * B->n_accounts);
     if (out->multisig_set_by) memcpy(out->multisig_set_by, hb.multisig_set_by.data(), 8 * B->n_accounts);
+    return 0;
+}
+
+// Replaces the ledger ciphertexts an uploaded batch starts from (its byte buffer holds them behind the records and the account keys).
+int32_t xhe_batch_set_ledger(xhe_ctx *ctx, xhe_batch *B, const uint8_t *balance_cts) {
+    if (!ctx || !B || (B->n_balances && !balance_cts)) return XHE_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    B->verified_ok = false;
+    if (!B->n_balances) return 0;
+    B->in_cts.assign(balance_cts, balance_cts + 64 * B->n_balances);
+    if (!B->hb.structural.accept || !B->bytes.p) return 0;              // nothing of the batch is on the device
+    HIPCHK(ctx, hipMemcpyAsync(B->bytes.as<u8>() + B->hb.cts_base, B->in_cts.data(), 64 * B->n_balances, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -704,8 +764,8 @@ int64_t xhe_batch_debug_read(xhe_ctx *ctx, xhe_batch *B, int32_t what, uint8_t *
 //    else RangeProof, a MIN over one key per part; a malformed record anywhere comes before all of them, as in the uncut path
 //    (every part is still parsed after an error);
 //  * a transaction that changes an account's multisig configuration decides which signer keys later transactions are checked
-//    against, and those keys lie in its own part's bytes: when one occurs in a part that is not the last, the call starts over
-//    uncut.
+//    against: the parts behind it are uploaded with a ledger view whose multisig configurations are the ones the parts so far
+//    leave (the uploads run in order on one thread).
 // Parts: XHE_SPLIT_PARTS (0 or 1: never; k: k parts whenever the batch has k transactions), else by the size of the records.
 static u32 split_parts_for(u64 n_txs, const u64 *offsets, const xhe_ledger_view *in) {
     if (n_txs < 2) return 1;
@@ -740,17 +800,22 @@ static void batch_free_finished(xhe_ctx *ctx, xhe_batch *b) {
     delete b;
 }
 
-// returns 1 when the call has to start over uncut (see above), else what xhe_verify_batch returns
+// returns 1 when the uncut path has to take the call (an inconsistent ledger view: it reports that), else what xhe_verify_batch returns
 static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, const xhe_ledger_out *out,
                                   xhe_verdict *verdict, const uint8_t rng_seed[32], u32 n_parts) {
     struct part { u64 lo = 0, hi = 0; std::vector<u64> offs; xhe_batch *B = nullptr; int32_t rc = 0; xhe_verdict structural{1, XHE_OK, -1}; };
     std::vector<part> parts(n_parts);
     {
-        // equal shares of the record bytes, at least one transaction each
+        // Shares of the record bytes, at least one transaction each.  The first part is smaller than the others (half their size;
+        // XHE_SPLIT_FIRST = its share in per cent of theirs): the device idles while the host parses it.
         const u64 rec_bytes = offsets[n_txs];
+        u64 first_pct = 50;
+        if (const char *e = getenv("XHE_SPLIT_FIRST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) first_pct = v; }
+        const u64 total_weight = first_pct + 100ull * (n_parts - 1);
         u64 lo = 0;
         for (u32 k = 0; k < n_parts; k++) {
-            u64 hi = k + 1 == n_parts ? n_txs : (u64)(std::lower_bound(offsets, offsets + n_txs, rec_bytes / n_parts * (k + 1)) - offsets);
+            const u64 cut = (u64)((unsigned __int128)rec_bytes * (first_pct + 100ull * k) / total_weight);
+            u64 hi = k + 1 == n_parts ? n_txs : (u64)(std::lower_bound(offsets, offsets + n_txs, cut) - offsets);
             hi = std::max(hi, lo + 1); hi = std::min(hi, n_txs - (n_parts - 1 - k));
             parts[k].lo = lo; parts[k].hi = hi;
             parts[k].offs.resize(hi - lo + 1);
@@ -766,6 +831,10 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     // XHE_SPLIT_OVERLAP=0: a part is enqueued only when the part in front has finished (the ledger passes through the host).
     const char *overlap_env = getenv("XHE_SPLIT_OVERLAP");
     const bool overlap = !(overlap_env && overlap_env[0] == '0');
+    // consecutive parts alternate between two pairs of streams and two bucket workspaces (XHE_SPLIT_LANES=0: all on one pair)
+    const char *lanes_env = getenv("XHE_SPLIT_LANES");
+    const bool lanes = overlap && !(lanes_env && lanes_env[0] == '0') && !getenv("XHE_ONE_STREAM");
+    u32 n_enqueued = 0;
     // (XHE_ONE_STREAM, diagnostics: the verification's ledger work runs on the main stream, so the hand-over does too)
     hipStream_t s0 = getenv("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];
     dev_buf ledger; ledger.pool = &ctx->pool;
@@ -778,18 +847,58 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     if (overlap) ctx->timer.level = 0;              // stage times are per verification; two are in flight here
     struct restore_level { stage_timer &t; int level; ~restore_level() { t.level = level; } } level_guard{ctx->timer, timing_level};
 
+    // the ledger's key maps are the same for every part: built once (an inconsistent view is the uncut path's error to report)
+    if (!ledger_index::view_consistent(*in)) return 1;
+    ledger_index index;
+    index.build(*in);
     std::mutex mu; std::condition_variable cv;
-    u32 uploaded = 0, verified = 0; bool stop = false, start_over = false;
+    u32 uploaded = 0, verified = 0; bool stop = false;
     std::thread uploader([&]() {
+        // The multisig configurations as the parts so far leave them.  A MultiSig transaction decides which signer keys the later
+        // transactions of its account are checked against (verify.rs:259-292, 401-428); for the parts behind it those keys are
+        // handed on as part of the ledger view they are uploaded with (the accounts and balances of the view stay the caller's).
+        struct ms_entry { bool present = false; u8 threshold = 0; std::vector<u8> signers; };
+        std::vector<ms_entry> ms;
+        std::vector<u32> ms_account, ms_offsets; std::vector<u8> ms_threshold, ms_signers;
+        xhe_ledger_view carried = *in;
+        bool ms_changed = false;
         for (u32 k = 0; k < n_parts; k++) {
             // at most two parts ahead of the last finished one (one ahead of the one the device is working on)
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || k <= verified + (overlap ? 2 : 1); }); if (stop) return; }
             part &p = parts[k];
-            p.rc = batch_upload_impl(ctx, records + offsets[p.lo], p.offs.data(), p.hi - p.lo, in, &p.B, &p.structural, false);
-            const bool redo = p.rc == 0 && p.B && p.B->hb.multisig_updated && k + 1 < n_parts;
-            { std::lock_guard<std::mutex> lk(mu); uploaded = k + 1; if (redo) start_over = true; }
+            p.rc = batch_upload_impl(ctx, records + offsets[p.lo], p.offs.data(), p.hi - p.lo, ms_changed ? &carried : in, &p.B, &p.structural, false, &index);
+            if (p.rc == 0 && p.B && p.B->hb.multisig_updated && k + 1 < n_parts) {
+                if (ms.empty()) {
+                    ms.resize(in->n_accounts);
+                    for (u64 i = 0; i < in->n_multisig; i++) {         // (the last entry of an account counts, as in the upload's walk)
+                        ms_entry &e = ms[in->multisig_account[i]];
+                        e.present = true; e.threshold = in->multisig_threshold[i];
+                        e.signers.assign(in->multisig_signers + 32ull * in->multisig_offsets[i], in->multisig_signers + 32ull * in->multisig_offsets[i + 1]);
+                    }
+                }
+                const std::vector<int64_t> &set_by = p.B->hb.multisig_set_by;
+                for (u64 a = 0; a < in->n_accounts; a++) {
+                    if (set_by[a] < 0) continue;
+                    // the record of a MultiSig transaction: 16-byte header (n_items = signers), pre-image = version, source, fee, nonce, threshold, signer keys
+                    const u8 *rec = records + offsets[p.lo + (u64)set_by[a]];
+                    const u32 n_signers = (u32)rec[2] | ((u32)rec[3] << 8);
+                    ms_entry &e = ms[a];
+                    e.present = n_signers != 0; e.threshold = rec[16 + 49];
+                    e.signers.assign(rec + 16 + 50, rec + 16 + 50 + 32ull * n_signers);
+                }
+                ms_account.clear(); ms_offsets.assign(1, 0u); ms_threshold.clear(); ms_signers.clear();
+                for (u64 a = 0; a < in->n_accounts; a++) {
+                    if (!ms[a].present) continue;
+                    ms_account.push_back((u32)a); ms_threshold.push_back(ms[a].threshold);
+                    ms_signers.insert(ms_signers.end(), ms[a].signers.begin(), ms[a].signers.end());
+                    ms_offsets.push_back((u32)(ms_signers.size() / 32));
+                }
+                carried.n_multisig = ms_account.size(); carried.multisig_account = ms_account.data(); carried.multisig_threshold = ms_threshold.data();
+                carried.multisig_offsets = ms_offsets.data(); carried.multisig_signers = ms_signers.data();
+                ms_changed = true;
+            }
+            { std::lock_guard<std::mutex> lk(mu); uploaded = k + 1; }
             cv.notify_all();
-            if (redo) return;
         }
     });
     std::vector<u8> cur;                               // (without overlap) the ledger's ciphertexts as the parts so far left them
@@ -811,7 +920,12 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
         xhe_verdict v{1, XHE_OK, -1};
         int32_t r = batch_verify_finish(ctx, B, &v);
         at(k, "verified");
-        if (r == 0) {
+        if (r == 0 && !v.accept && v.err_code == XHE_ERR_MALFORMED) {
+            // a scalar that is not canonical, found by the device's check of this part: malformed records come before every other
+            // error, the one with the lowest index first; nothing behind this part can change the verdict
+            malformed_key = std::min(malformed_key, split_verdict_key(v, p.lo));
+            skip_verify = true;
+        } else if (r == 0) {
             const u64 vk = split_verdict_key(v, p.lo);
             key = std::min(key, vk);
             if (!v.accept && (vk >> 60) == 0) skip_verify = true;      // a per-transaction error: nothing behind it can come first but a malformed record
@@ -826,9 +940,9 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
                 if (e != hipSuccess) { set_error(ctx, std::string("reading a part's ledger back: ") + hipGetErrorString(e)); r = XHE_E_HIP; }
                 else for (u64 u = 0; u < n_slots; u++) memcpy(cur.data() + 64ull * hb.slot_of_used[u], fin.data() + 64 * u, 64);
             }
-            if (k + 1 == n_parts && hb.multisig_updated) {
-                ms_set_by = hb.multisig_set_by;
-                for (auto &x : ms_set_by) if (x >= 0) x += (int64_t)p.lo;
+            if (hb.multisig_updated) {            // (the parts finish in order: a later part's set-up of an account replaces an earlier one's)
+                if (ms_set_by.empty()) ms_set_by.assign(in->n_accounts, -1);
+                for (u64 a = 0; a < in->n_accounts; a++) if (hb.multisig_set_by[a] >= 0) ms_set_by[a] = hb.multisig_set_by[a] + (int64_t)p.lo;
             }
         }
         if (r == 0 && overlap) { hipError_t e = hipEventSynchronize(B->ev_carried); if (e != hipSuccess) { set_error(ctx, std::string("waiting for a part's ledger: ") + hipGetErrorString(e)); r = XHE_E_HIP; } }
@@ -839,7 +953,6 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     };
     int64_t in_flight = -1;                            // the part whose verification is enqueued and not finished
     for (u32 k = 0; k < n_parts && rc == 0; k++) {
-        bool redo;
         // Whichever comes first: the part's upload (it is then enqueued behind the part in flight), or the end of the part in
         // flight (it is then finished while the upload goes on -- an upload that has to rebuild the context's tables for larger
         // proofs even waits for that).
@@ -848,42 +961,50 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
             if (hipEventQuery(parts[(size_t)in_flight].B->ev_done) != hipErrorNotReady) { rc = finish_part((u32)in_flight); in_flight = -1; }
         }
         if (rc != 0) break;
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); redo = start_over; }
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return uploaded > k; }); }
         at(k, "uploaded");
         part &p = parts[k];
         rc = p.rc;
-        if (rc == 0 && redo) { rc = 1; break; }
-        if (rc == 0 && !p.structural.accept) { malformed_key = split_verdict_key(p.structural, p.lo); break; }
+        if (rc == 0 && !p.structural.accept) { malformed_key = std::min(malformed_key, split_verdict_key(p.structural, p.lo)); break; }
         if (rc == 0 && !overlap && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
         if (rc == 0 && !skip_verify) {
             xhe_batch *B = p.B;
             const host_batch &hb = B->hb;
+            // the stream this part's ledger inputs are decoded on: side stream 1 with lanes (batch_verify_enqueue), else side stream 0
+            hipStream_t s_in = lanes ? ctx->side[1] : s0;
             if (k > 0 && in->n_balances) {
-                // the ciphertexts this part starts from, behind its upload and in front of its ledger decode
-                hipError_t e = hipStreamWaitEvent(s0, B->ev_uploaded, 0);
-                if (e == hipSuccess) e = overlap ? hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, ledger.p, 64 * in->n_balances, hipMemcpyDeviceToDevice, s0)
-                                                 : hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, cur.data(), 64 * in->n_balances, hipMemcpyHostToDevice, s0);
-                if (e == hipSuccess && !overlap) e = hipStreamSynchronize(s0);
+                // the ciphertexts this part starts from, behind its upload, behind the hand-over of the part in front (a part that
+                // has finished has handed over) and in front of its ledger decode
+                hipError_t e = hipStreamWaitEvent(s_in, B->ev_uploaded, 0);
+                if (e == hipSuccess && overlap && in_flight >= 0) e = hipStreamWaitEvent(s_in, parts[(size_t)in_flight].B->ev_carried, 0);
+                if (e == hipSuccess) e = overlap ? hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, ledger.p, 64 * in->n_balances, hipMemcpyDeviceToDevice, s_in)
+                                                 : hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, cur.data(), 64 * in->n_balances, hipMemcpyHostToDevice, s_in);
+                if (e == hipSuccess && !overlap) e = hipStreamSynchronize(s_in);
                 if (e != hipSuccess) { set_error(ctx, std::string("handing the ledger to the next part of the batch: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
             }
             u8 seed[32]; memcpy(seed, rng_seed, 32); seed[31] ^= (u8)k; seed[30] ^= (u8)(k >> 8);      // independent batch factors per part
-            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, in_flight < 0);
+            const int lane = lanes ? (int)(n_enqueued & 1) : -1;
+            u32 *carry = overlap ? ledger.as<u32>() : nullptr;
+            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, in_flight < 0, lane, carry);
             if (rc == ENQUEUE_TABLES_BUSY) {
                 rc = finish_part((u32)in_flight); in_flight = -1;
-                if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, true);
+                if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, true, lane, carry);
             }
-            if (rc == 0 && overlap) {
-                launch_ledger_carry(s0, B->final_cts.as<u32>(), B->slot_of_used.as<u32>(), (u32)hb.slot_of_used.size(), ledger.as<u32>());
-                hipError_t e = hipGetLastError();
-                if (e == hipSuccess) e = hipEventRecord(B->ev_carried, s0);
-                if (e != hipSuccess) { set_error(ctx, std::string("handing a part's ledger on: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
-            }
+            if (rc == 0) n_enqueued++;
             at(k, "enqueued");
             if (rc == 0 && in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
             if (rc == 0) in_flight = k;
         } else if (rc == 0) {
-            // nothing to verify behind a per-transaction error: the part was parsed for malformed records only
+            // nothing to verify behind a per-transaction error: the part was parsed for malformed records only (the scalars' range
+            // check ran on the device with its upload)
             if (in_flight >= 0) { rc = finish_part((u32)in_flight); in_flight = -1; }
+            if (rc == 0 && p.B && p.B->noncanonical.p && malformed_key == ~0ull) {
+                u32 first = 0xffffffffu;
+                hipError_t e = hipEventSynchronize(p.B->ev_uploaded);
+                if (e == hipSuccess) e = hipMemcpy(&first, p.B->noncanonical.p, 4, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) { set_error(ctx, std::string("reading a part's scalar check back: ") + hipGetErrorString(e)); rc = XHE_E_HIP; }
+                else if (first != 0xffffffffu) malformed_key = split_verdict_key(xhe_verdict{0, XHE_ERR_MALFORMED, (int64_t)first}, p.lo);
+            }
             if (p.B) { xhe_batch_free(ctx, p.B); p.B = nullptr; }
             mark_verified(k);
         }
@@ -1088,10 +1209,26 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
 // rebuild is waiting for the verifications in flight, the shared lock is not waited for -- ENQUEUE_TABLES_BUSY tells the caller to
 // finish what it has in flight (which lets the rebuild through) and to call again.  Waiting here instead would rely on the
 // lock letting new readers pass a waiting writer.
-static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */, bool may_block) {
+//
+// lane (parts of a batch verified in parts): consecutive parts alternate between two lanes.  Lane 1 swaps the roles of the main
+// stream and side stream 0 and uses a bucket workspace of its own, so the main chain of part k + 1 (transcripts, proof scalars, bucket
+// sort -- none of which needs a decoded point) queues behind the short ledger and static-generator work of part k instead of behind
+// part k's whole multiscalar check, and runs beside it; part k + 1's ledger scan in turn queues behind part k's main chain, which
+// it could not overtake anyway (its inputs are the ciphertexts part k leaves).  For that the part's early decode (the ledger's
+// and the transfers' ciphertexts) moves to side stream 1, in front of the bulk decode.  Parts two apart share streams and
+// workspace in stream order.
+// lane_or_none = -1: no lanes (a single verification, or a run of independent batches); carry_ledger: the device array of the whole
+// ledger's ciphertexts that a part writes the slots it used into, right behind its ledger scan (B->ev_carried fires then).
+static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */, bool may_block,
+                                    int lane_or_none, u32 *carry_ledger) {
     const host_batch &hb = B->hb;
-    hipStream_t st = ctx->stream;
+    // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
+    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
+    const bool lanes = lane_or_none >= 0 && !one_stream;
+    const u32 lane = lanes ? (u32)lane_or_none & 1u : 0u;
+    hipStream_t st = lane ? ctx->side[0] : ctx->stream;
     B->verified_ok = false; B->in_flight = false; B->trivial = false;
+    B->lane = lane; B->main_stream = st; B->ledger_stream = one_stream ? st : (lane ? ctx->stream : ctx->side[0]);
     if (!hb.structural.accept) return 0;
     const u32 n_txs = (u32)hb.n_txs, n_cm = hb.n_cm, n_xf = hb.n_xf, n_dec = hb.n_decs;
     const u32 n_ops = hb.n_ops, n_slots = (u32)hb.slot_of_used.size(), n_sigs = hb.n_sigs;
@@ -1110,8 +1247,6 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
         if (!B->tables_lock.owns_lock()) return ENQUEUE_TABLES_BUSY;
     }
     B->in_flight = true;
-    // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
-    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
     // The fills that open a verification run on the main stream, or (setup_on_side: a batch verified in parts) on side stream 1,
     // which is free long before the main stream has finished the part in front: the part's decoding and signatures then start
     // beside the multiscalar check of the part before.
@@ -1157,7 +1292,9 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     //   main     transcripts -> proof scalars -> multiscalar check -> verdict
     //   side 0   ledger inputs -> ledger scan (its points feed the multiscalar check) -> static-generator scalars -> ledger encodings, point errors
     //   side 1   every other point of the batch (public keys included) -> signature points + hashing -> end of the signature hashes
-    hipStream_t s0 = one_stream ? st : ctx->side[0], s1 = one_stream ? st : ctx->side[1];
+    hipStream_t s0 = B->ledger_stream, s1 = one_stream ? st : ctx->side[1];
+    // a part of a batch verified in parts decodes the ledger scan's inputs on side stream 1 (see `lane` above)
+    const bool early_on_s1 = lanes;
     HIPCHK(ctx, tm.mark("transcript", st));
     launch_transcript(st, bytes, txs, cms, xfers, B->tmpl.as<u32>(), B->segs.as<u32>(), hb.tr_plan, B->tr_list.as<u32>(), B->tr_tiles.as<transcript_tile>(),
                       B->tr_stream.as<u64>(), B->serial_txs.as<u32>(), (u32)hb.serial_txs.size(), chal, tx_err, rp_err);
@@ -1169,9 +1306,16 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     const bool own_sig_stream = n_txs >= sig_stream_min_txs();
     hipStream_t ssig = one_stream ? st : (own_sig_stream ? ctx->side[2] : s1);
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
-    HIPCHK(ctx, tm.open("decode_first", s0));
-    launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
-    HIPCHK(ctx, tm.close("decode_first", s0));
+    if (early_on_s1) {
+        HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
+        launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_early, s1));
+        HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_early, 0));
+    } else {
+        HIPCHK(ctx, tm.open("decode_first", s0));
+        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
+        HIPCHK(ctx, tm.close("decode_first", s0));
+    }
     auto enqueue_scan = [&]() -> int32_t {
         HIPCHK(ctx, tm.open("ledger_scan", s0));
         launch_ledger_scan(s0, B->ops.as<dev_op>(), n_ops, pts, ctx->gtab.as<u32>(), B->thread_excl.as<u32>(), B->block_tot.as<u32>(), B->slot_last_op.as<u32>(),
@@ -1181,6 +1325,11 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
         // a batch verified in parts: the next part waits for the resulting ledger ciphertexts (otherwise they are written at the
         // end of this stream's work, off the path to the verdict)
         if (n_ops && setup_on_side) launch_ledger_final(s0, B->slot_final.as<u32>(), B->slot_base.as<u32>(), n_slots, B->final_cts.as<u32>());
+        if (carry_ledger) {
+            launch_ledger_carry(s0, B->final_cts.as<u32>(), B->slot_of_used.as<u32>(), n_slots, carry_ledger);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipEventRecord(B->ev_carried, s0));
+        }
         return 0;
     };
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
@@ -1258,14 +1407,20 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     msm_deps deps;
     deps.points_ready[0] = ctx->ev_side_done[0]; deps.points_ready[1] = ctx->ev_side_done[2];
     if (use_tables) { deps.extra_point = B->static_sum.as<u32>(); deps.extra_ready = ctx->ev_static_done; }
-    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps);
+    B->acc_timed = false;
+    if (ctx->stats_on) {
+        for (hipEvent_t &e : B->ev_acc) if (!e) HIPCHK(ctx, hipEventCreate(&e));
+        B->acc_timed = true;
+    }
+    int32_t rc = msm_device(ctx, scalars, pts, term_point, hb.n_points, use_tables ? hb.static_term_off : hb.n_terms, B->verdict.as<u32>() + 4, false, true, deps, st, lane,
+                            B->acc_timed ? B->ev_acc : nullptr);
     if (rc) return rc;
     host_mark("multiscalar check enqueued");
     HIPCHK(ctx, tm.mark("join_signatures", st));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side_done[1], 0));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_points_checked, 0));
     HIPCHK(ctx, tm.mark("verdict", st));
-    launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2);
+    launch_verdict(st, tx_err, rp_err, n_txs, B->verdict.as<unsigned long long>(), B->verdict.as<u32>() + 2, B->noncanonical.as<u32>());
     HIPCHK(ctx, tm.mark("end", st));
     B->verdict_words = ctx->verdict_host + 16 * (ctx->verdict_next++ % VERDICT_SLOTS);
     HIPCHK(ctx, hipMemcpyAsync(B->verdict_words, B->verdict.p, 64, hipMemcpyDeviceToHost, st));
@@ -1278,7 +1433,7 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
 // reference reports with a second, sigma-only check.
 static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict) {
     const host_batch &hb = B->hb;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = B->main_stream ? B->main_stream : ctx->stream;
     if (!hb.structural.accept) { *verdict = hb.structural; return 0; }
     struct unlock_on_exit { xhe_batch *b; ~unlock_on_exit() { b->in_flight = false; if (b->tables_lock.owns_lock()) b->tables_lock.unlock(); } } unlock{B};
     if (!B->in_flight) { set_error(ctx, "no verification of this batch is in flight"); return XHE_E_ARG; }
@@ -1295,6 +1450,13 @@ static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verd
     const u32 *host = B->verdict_words;
     u64 first_err = (u64)host[0] | ((u64)host[1] << 32);
     u32 first_rp = host[2], merged_identity = host[12];
+    if (B->acc_timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, B->ev_acc[0], B->ev_acc[1]) == hipSuccess) { ctx->stats.launches++; ctx->stats.accumulate_ms += ms; ctx->stats.entries += host[13]; ctx->stats.terms_nonzero += host[14]; }
+        B->acc_timed = false;
+    }
+    // a scalar that is not canonical: the reference would not have deserialised the record, whatever else is wrong with the batch
+    if (host[3] != 0xffffffffu) { *verdict = {0, XHE_ERR_MALFORMED, (int64_t)host[3]}; return 0; }
     if (first_err != ~0ull) { *verdict = {0, (int32_t)(first_err & 0xff), (int64_t)(first_err >> 32)}; return 0; }
     if (merged_identity && first_rp == 0xffffffffu) { *verdict = {1, XHE_OK, -1}; B->verified_ok = true; return 0; }
     // Slow path (a proof is wrong): decide between GenericProof and RangeProof as the reference orders them
@@ -1314,7 +1476,7 @@ static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verd
         // reuse k_static_terms with nm_cap = 0: writes only the B and H scalars
         launch_static_terms(st, B->gh_sums.as<u32>(), sb, B->rp_acc.as<u32>(), 0u, n_sig_terms, s2.as<u32>(), tp2.as<u32>());
         HIPCHK(ctx, hipMemsetAsync(r2.p, 0, 64, st));
-        rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false, false);
+        rc = msm_device(ctx, s2.as<u32>(), pts, tp2.as<u32>(), hb.n_points, (u64)n_sig_terms + 2, r2.as<u32>(), false, false, msm_deps(), st, B->lane);
         u32 h2[16];
         if (rc == 0) { hipError_t e = hipMemcpyAsync(h2, r2.p, 64, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipStreamSynchronize(st); if (e != hipSuccess) rc = XHE_E_HIP; }
         if (rc) return rc;

@@ -54,9 +54,13 @@ static inline bool rec_scalars_canonical(const u8 *p, int count) {
     return true;
 }
 
+static inline bool record_scalars_canonical(const tx_record &t);
+
 // false = the record would not have deserialised in the reference (wrong lengths, non-canonical scalars,
-// RangeProof::from_bytes / InnerProductProof::from_bytes format errors)
-static inline bool record_parse(tx_record &t, const u8 *rec, u64 len) {
+// RangeProof::from_bytes / InnerProductProof::from_bytes format errors).  check_scalars = false leaves the scalars' range
+// check (record_scalars_canonical, which touches every part of the record) to the caller: the batch upload has the device do
+// it (k_expand_descriptors), where the record's bytes are read anyway.
+static inline bool record_parse(tx_record &t, const u8 *rec, u64 len, bool check_scalars = true) {
     if (len < 16 || len > 0x7fffffffull) return false;
     t.base = rec;
     t.type = rec[0]; t.flags = rec[1]; t.n_items = (u16)rec_le16(rec + 2); t.n_commitments = (u16)rec_le16(rec + 4);
@@ -100,13 +104,17 @@ static inline bool record_parse(tx_record &t, const u8 *rec, u64 len) {
     t.cm_off = t.rp_off + t.rp_len;
     t.ms_off = t.pre_off + t.pre_len;
     t.sig_off = t.ms_off + 65u * t.n_multisig;
+    if (t.rp_len % 32 != 0 || t.rp_len < 9 * 32 || ((t.rp_len / 32 - 9) & 1) || t.lg() >= 32) return false;
+    return !check_scalars || record_scalars_canonical(t);
+}
+// every scalar of a parsed record is below the group order: the proofs' responses, the signatures, the range proof's
+// t_x, t_x_blinding, e_blinding, a, b (Scalar::from_canonical_bytes in the reference's deserialisation)
+static inline bool record_scalars_canonical(const tx_record &t) {
     for (size_t i = 0; i < t.transfer_off.size(); i++) if (!rec_scalars_canonical(t.transfer_proof(i) + 96, 2)) return false;
     for (u32 i = 0; i < t.n_commitments; i++) if (!rec_scalars_canonical(t.commitment(i) + 64 + 96, 3)) return false;
     if (!rec_scalars_canonical(t.signature(), 2)) return false;
     for (u32 i = 0; i < t.n_multisig; i++) if (!rec_scalars_canonical(t.ms_entry(i) + 1, 2)) return false;
-    if (t.rp_len % 32 != 0 || t.rp_len < 9 * 32 || ((t.rp_len / 32 - 9) & 1) || t.lg() >= 32) return false;
-    if (!rec_scalars_canonical(t.rp() + 128, 3) || !rec_scalars_canonical(t.rp() + t.rp_len - 64, 2)) return false;
-    return true;
+    return rec_scalars_canonical(t.rp() + 128, 3) && rec_scalars_canonical(t.rp() + t.rp_len - 64, 2);
 }
 
 static inline bool rec_is_zero32(const u8 *p) { u8 a = 0; for (int i = 0; i < 32; i++) a |= p[i]; return a == 0; }

@@ -153,6 +153,9 @@ struct expand_args {
     const dev_dec *shared_decs; const u32 *shared_early, *shared_key, *slot_pos, *slot_base;
     u32 n_shared, n_shared_early, n_shared_key, n_slots, blk_end, early_end, key_end;
     u32 *slot_last_op;
+    // the scalars' range check (record_scalars_canonical, xhe_record.h) on the device: the smallest index of a transaction with a
+    // scalar that is not below the group order, by atomicMin (0xffffffff before the launch)
+    const u8 *bytes; u32 *noncanonical_first;
 };
 
 }  // namespace xhe

@@ -9,6 +9,12 @@ both the AND of the ranks' accept bits and the reference's error precedence: per
 batch order first (verify.rs:492-498), then GenericProof, then RangeProof (verify.rs:500-514).
 With torch.distributed backend "nccl" the all-reduce is RCCL over xGMI; with "gloo" the tensors are
 host tensors.
+
+When the account groups do not balance (one sender for the whole batch, /root/reference/benches/tx.rs:129-189) the library
+plans consecutive ranges instead (xhe_plan_shards).  Range s must start from the ledger the ranges before it leave: the ranks
+pass the ledger's ciphertexts along -- rank s applies its range (Transaction::apply_without_verify, verify.rs:545-619, the
+ledger arithmetic alone) to the state it received and broadcasts the result -- and every rank verifies its range against the
+state it started from.  That broadcast chain is the one exchange of ledger data in the path.
 """
 import ctypes
 
@@ -24,6 +30,12 @@ def _lib():
         lib.xhe_partition_batch.restype = ctypes.c_int32
         lib.xhe_partition_batch.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
                                             ctypes.POINTER(ctypes.c_int64)]
+        lib.xhe_plan_shards.restype = ctypes.c_int32
+        lib.xhe_plan_shards.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+        lib.xhe_slice_shard.restype = ctypes.c_int32
+        lib.xhe_slice_shard.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         lib.xhe_verdict_key.restype = ctypes.c_uint64
         lib.xhe_verdict_key.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64]
         lib.xhe_verdict_from_key.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
@@ -77,6 +89,68 @@ def partition(records, world_size):
     return shards
 
 
+def plan(records, world_size):
+    """(transaction indices per rank, consecutive_ranges) as xhe_verify_batch_sharded itself cuts a batch (xhe_plan_shards):
+    account groups, or consecutive ranges of equal weight when the groups do not balance."""
+    n = len(records)
+    blob = b"".join(records)
+    offs = [0]
+    for r in records:
+        offs.append(offs[-1] + len(r))
+    offsets = (ctypes.c_uint64 * (n + 1))(*offs)
+    shard_of = (ctypes.c_uint32 * max(n, 1))()
+    bad, ranges = ctypes.c_int64(-1), ctypes.c_int32(0)
+    rc = _lib().xhe_plan_shards(blob, offsets, n, world_size, shard_of, ctypes.byref(ranges), ctypes.byref(bad))
+    if rc == 1:
+        raise MalformedRecord(int(bad.value))
+    if rc != 0:
+        raise XheError("xhe_plan_shards failed: %d" % rc)
+    shards = [[] for _ in range(world_size)]
+    for i in range(n):
+        shards[shard_of[i]].append(i)
+    return shards, bool(ranges.value)
+
+
+def cut_for_ranks(batch, world_size):
+    """A synthetic batch (api.SyntheticBatch) cut into one piece per rank inside the library (xhe_plan_shards + xhe_slice_shard): per
+    rank a dict of numpy arrays -- records (uint8), offsets (uint64), index (uint64: the transactions' positions in the whole batch),
+    and the ledger's keys, assets, cts (uint8) and balance_account (uint32).  Every rank gets the whole ledger arrays of the
+    synthetic batch (a few kilobytes per account group); the records, which are the bulk, are cut."""
+    import numpy as np
+    lib = _lib()
+    n = batch.n_txs
+    shard_of = (ctypes.c_uint32 * max(n, 1))()
+    bad, ranges = ctypes.c_int64(-1), ctypes.c_int32(0)
+    rc = lib.xhe_plan_shards(batch.records, batch.offsets, n, world_size, shard_of, ctypes.byref(ranges), ctypes.byref(bad))
+    if rc != 0:
+        raise XheError("xhe_plan_shards failed: %d (first malformed record %d)" % (rc, bad.value))
+    if ranges.value:
+        raise XheError("the batch's account groups do not balance over %d ranks: consecutive ranges need the ledger passed along (verify_batch_sharded)" % world_size)
+
+    class RawView(ctypes.Structure):
+        _fields_ = [("n_accounts", ctypes.c_uint64), ("account_keys", ctypes.c_void_p), ("account_nonces", ctypes.c_void_p), ("n_balances", ctypes.c_uint64),
+                    ("balance_account", ctypes.c_void_p), ("balance_assets", ctypes.c_void_p), ("balance_cts", ctypes.c_void_p)]
+    rv = ctypes.cast(batch.view, ctypes.POINTER(RawView)).contents
+    ledger = {"keys": np.frombuffer(ctypes.string_at(rv.account_keys, 32 * rv.n_accounts), dtype=np.uint8),
+              "assets": np.frombuffer(ctypes.string_at(rv.balance_assets, 32 * rv.n_balances), dtype=np.uint8),
+              "cts": np.frombuffer(ctypes.string_at(rv.balance_cts, 64 * rv.n_balances), dtype=np.uint8),
+              "balance_account": np.frombuffer(ctypes.string_at(rv.balance_account, 4 * rv.n_balances), dtype=np.uint32)}
+    pieces = []
+    for s in range(world_size):
+        n_local, n_bytes = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.xhe_slice_shard(batch.records, batch.offsets, n, shard_of, s, None, None, None, ctypes.byref(n_local), ctypes.byref(n_bytes))
+        recs = np.zeros(max(n_bytes.value, 1), dtype=np.uint8)
+        offs = np.zeros(n_local.value + 1, dtype=np.uint64)
+        index = np.zeros(max(n_local.value, 1), dtype=np.uint64)
+        rc = lib.xhe_slice_shard(batch.records, batch.offsets, n, shard_of, s, recs.ctypes.data, offs.ctypes.data, index.ctypes.data, ctypes.byref(n_local), ctypes.byref(n_bytes))
+        if rc != 0:
+            raise XheError("xhe_slice_shard failed: %d" % rc)
+        piece = {"records": recs[:n_bytes.value], "offsets": offs, "index": index[:n_local.value]}
+        piece.update(ledger)
+        pieces.append(piece)
+    return pieces
+
+
 def verdict_key(accept, err_code, first_bad_local, shard):
     """The 63-bit key a rank contributes to the MIN all-reduce (xhe_verdict_key): per-transaction errors order by their index in
     the whole batch, then GenericProof, then RangeProof."""
@@ -118,17 +192,76 @@ def merge_ledger_bytes(own_cts, owned_mask, dist, device=None):
     return bytes(merged), count
 
 
-def verify_batch_sharded(verify_fn, txs, ledger, dist, device=None):
+def _verify_ranges(verify_fn, apply_fn, txs, ledger, shards, dist, device):
+    """Consecutive ranges: the ledger's ciphertexts pass from rank to rank (one broadcast per rank, in order), every rank verifies
+    its range against the state it started from.  A rank whose apply fails says so with its broadcast: the ranks behind it do
+    not verify (its own verification reports the error, which comes first)."""
+    import torch
+    from .api import LedgerOut
+    rank, world = dist.get_rank(), dist.get_world_size()
+    f = ledger.flatten()
+    n_slots = len(f["slots"])
+    cur = bytearray(f["balance_cts"])
+    my_start, chain_ok = None, True
+    for s in range(world):
+        if s == rank and chain_ok:             # the chain is intact up to here: this rank has a state to start from
+            my_start = bytes(cur)
+        payload = torch.zeros(64 * n_slots + 1, dtype=torch.uint8)
+        if s == rank and chain_ok:
+            after = apply_fn([txs[i] for i in shards[s]], ledger, bytes(cur))
+            if after is None:
+                payload[0] = 1
+            else:
+                payload[1:] = torch.frombuffer(bytearray(after), dtype=torch.uint8)
+        elif s == rank:
+            payload[0] = 1
+        if device is not None:
+            payload = payload.to(device)
+        dist.broadcast(payload, src=s)
+        payload = payload.cpu()
+        if int(payload[0]) != 0:
+            chain_ok = False
+        elif chain_ok:
+            cur = bytearray(payload[1:].numpy().tobytes())
+    # this rank's range against the state it started from (ranks behind a broken chain have no such state: they contribute nothing;
+    # the rank the chain broke at verifies and names the error)
+    key = ACCEPT_KEY
+    if my_start is not None:
+        start = ledger.clone()
+        for i, (acc_i, asset) in enumerate(f["slots"]):
+            start.accounts[f["keys"][acc_i]].balances[asset] = my_start[64 * i:64 * i + 64]
+        f2 = start.flatten()
+        out = LedgerOut((ctypes.c_uint8 * max(64 * n_slots, 1))(), (ctypes.c_uint64 * max(len(f2["keys"]), 1))(), (ctypes.c_int64 * max(len(f2["keys"]), 1))())
+        accept, code, first_bad = verify_fn([txs[i] for i in shards[rank]], f2, out)
+        key = verdict_key(accept, code, first_bad, shards[rank])
+    key = all_reduce_min(key, dist, device)
+    ok, code, first = decode_key(key)
+    if not ok:
+        return False, code, first
+    if not chain_ok:                           # cannot happen with an accepting verdict: an apply failure is a verification failure
+        return False, codes.ERR_STATE, -1
+    ledger.absorb(f, bytes(cur), [int(x) for x in f["nonces"]][:len(f["keys"])], [-1] * len(f["keys"]), txs)
+    return True, codes.OK, -1
+
+
+def verify_batch_sharded(verify_fn, txs, ledger, dist, device=None, apply_fn=None):
     """Transaction::verify_batch over all ranks of `dist` (an initialised torch.distributed).
 
     verify_fn(shard_txs, flat_ledger, out: LedgerOut) -> (accept, err_code, first_bad_local) verifies one
-    shard against the flattened ledger and, on accept, fills `out`.  Returns the batch's
-    (accept, err_code, first_bad_tx), identical on every rank; on accept `ledger` holds the merged state.
+    shard against the flattened ledger and, on accept, fills `out`.  apply_fn(range_txs, ledger, start_cts) -> the ledger's
+    ciphertexts (bytes, slot order of ledger.flatten()) after the range was applied to start_cts, or None when the apply fails;
+    with it, batches whose account groups do not balance are cut into consecutive ranges (see the module's head).  Returns the
+    batch's (accept, err_code, first_bad_tx), identical on every rank; on accept `ledger` holds the merged state.
     """
     from .api import LedgerOut
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        shards = partition([t.record for t in txs], world)
+        if apply_fn is not None:
+            shards, ranges = plan([t.record for t in txs], world)
+            if ranges:
+                return _verify_ranges(verify_fn, apply_fn, txs, ledger, shards, dist, device)
+        else:
+            shards = partition([t.record for t in txs], world)
     except MalformedRecord as e:              # every rank sees the same records: the same verdict everywhere, nothing to reduce
         return False, codes.ERR_MALFORMED, e.index
     mine = shards[rank]
@@ -181,4 +314,36 @@ def gpu_verify_fn(engine, seed=None):
         engine._check(_lib().xhe_verify_batch(engine.ctx, blob, offsets, len(shard_txs), ctypes.byref(f["view"]), ctypes.byref(out), ctypes.byref(v),
                                               _fresh_seed(seed)))
         return bool(v.accept), int(v.err_code), int(v.first_bad_tx)
+    return run
+
+
+def gpu_apply_fn(engine):
+    """apply_fn over the HIP path: Transaction::apply_without_verify for a range (xhe_batch_upload with the starting ciphertexts,
+    xhe_batch_apply, xhe_batch_read_ledger)."""
+    from .api import LedgerOut, Verdict, _lib
+
+    def run(range_txs, ledger, start_cts):
+        lib = _lib()
+        lib.xhe_batch_upload.restype = lib.xhe_batch_apply.restype = lib.xhe_batch_read_ledger.restype = lib.xhe_batch_set_ledger.restype = ctypes.c_int32
+        f = ledger.flatten()
+        blob = b"".join(t.record for t in range_txs)
+        offs = [0]
+        for t in range_txs:
+            offs.append(offs[-1] + len(t.record))
+        offsets = (ctypes.c_uint64 * len(offs))(*offs)
+        ctx, handle, v = ctypes.c_void_p(engine.ctx), ctypes.c_void_p(), Verdict()
+        engine._check(lib.xhe_batch_upload(ctx, blob, offsets, ctypes.c_uint64(len(range_txs)), ctypes.byref(f["view"]), ctypes.byref(handle), ctypes.byref(v)))
+        try:
+            if not v.accept:
+                return None
+            engine._check(lib.xhe_batch_set_ledger(ctx, handle, start_cts))
+            engine._check(lib.xhe_batch_apply(ctx, handle, ctypes.byref(v)))
+            if not v.accept:
+                return None
+            cts = (ctypes.c_uint8 * max(64 * len(f["slots"]), 1))()
+            out = LedgerOut(cts, None, None)
+            engine._check(lib.xhe_batch_read_ledger(ctx, handle, ctypes.byref(out)))
+            return bytes(cts)[:64 * len(f["slots"])]
+        finally:
+            lib.xhe_batch_free(ctx, handle)
     return run
