@@ -76,8 +76,10 @@ def measured_valu_instructions(tag):
 
 
 def gather_calibration():
-    """FETCH_SIZE bytes reported per byte really fetched for the accumulation kernel's access shape (six 16-byte LDS-DMA loads per
-    lane from a random 128-byte record), from the committed run of tools/ubench_gather; None when not committed."""
+    """The committed run of tools/calibrate_gather.sh: `fetch_size_factor` = bytes of the 128-byte lines really fetched per byte that
+    FETCH_SIZE reports, for the accumulation kernel's access shape (six 16-byte LDS-DMA loads per lane from a random 128-byte
+    record; 1.05 here, against 2.0 for a coalesced streaming read), and `gather_line_GBps`, the rate the memory system sustains
+    for that shape on a table beyond the on-die cache; None when not committed."""
     path = os.path.join(ROOT, "profiles", "r03_gather_calibration.json")
     if not os.path.exists(path):
         return None
@@ -302,9 +304,15 @@ def attach_traffic(roofline, tag, launches_per_step_in_profile=None):
     corr = float(cal["fetch_size_factor"]) if cal else 1.0
     roofline["traffic"] = int(fetch * corr + write)
     roofline["traffic_correction"] = {"fetch_size_factor": corr, "fetch_size_reported": fetch, "write_size_reported": write,
-                                      "source": ("profiles/r03_gather_calibration.json: FETCH_SIZE reported / bytes requested for this kernel's access shape "
+                                      "source": ("profiles/r03_gather_calibration.json: bytes of the lines fetched per byte FETCH_SIZE reports, for this kernel's access shape "
                                                  "(six 16-byte LDS-DMA loads per lane from a random 128-byte record)") if cal else "no calibration committed: counters as reported"}
     roofline["traffic_source"] = "FETCH_SIZE x factor + WRITE_SIZE of the kernel per launch, newest committed rocprofv3 --pmc passes of this workload under profiles/"
+    if cal and cal.get("gather_line_GBps") and roofline.get("kernel_ms"):
+        # the bytes the kernel really moves (one point record per entry and window, not one per term) against the rate measured for
+        # exactly this access shape: how close the kernel is to the memory system, beside the contractual HBM line above
+        rate = roofline["traffic"] / (roofline["kernel_ms"] * 1e-3) / 1e9
+        roofline["gather"] = {"achieved": round(rate, 1), "peak": float(cal["gather_line_GBps"]), "unit": "GB/s", "frac": round(rate / float(cal["gather_line_GBps"]), 4),
+                              "what": "measured traffic per launch / launch time against the random 128-byte-record gather rate of tools/ubench_gather (table of 2 GiB, every record once)"}
 
 
 def valu_issue_of(roofline, tag, torch, local_rank):

@@ -260,6 +260,18 @@ __device__ __forceinline__ sc prf_scalar_128(const u32 *__restrict__ seed8, u32 
     u32 w[8] = {(u32)st[0] | 1u, (u32)(st[0] >> 32), (u32)st[1], (u32)(st[1] >> 32), 0, 0, 0, 0};
     return sc_from_words(w);
 }
+// three independent odd factors of `bits` bits (128..191) from one state
+__device__ __forceinline__ void prf_scalar_x3(sc &a, sc &b, sc &c, const u32 *__restrict__ seed8, u32 domain, u64 index, u32 bits) {
+    u64 st[25];
+    prf_state(st, seed8, domain, index);
+    const u64 top = (bits >= 192) ? ~0ull : ((1ull << (bits - 128)) - 1);
+    u32 w[8] = {(u32)st[0] | 1u, (u32)(st[0] >> 32), (u32)st[1], (u32)(st[1] >> 32), (u32)(st[2] & top), (u32)((st[2] & top) >> 32), 0, 0};
+    a = sc_from_words(w);
+    w[0] = (u32)st[3] | 1u; w[1] = (u32)(st[3] >> 32); w[2] = (u32)st[4]; w[3] = (u32)(st[4] >> 32); w[4] = (u32)(st[5] & top); w[5] = (u32)((st[5] & top) >> 32);
+    b = sc_from_words(w);
+    w[0] = (u32)st[6] | 1u; w[1] = (u32)(st[6] >> 32); w[2] = (u32)st[7]; w[3] = (u32)(st[7] >> 32); w[4] = (u32)(st[8] & top); w[5] = (u32)((st[8] & top) >> 32);
+    c = sc_from_words(w);
+}
 __device__ __forceinline__ void prf_scalar_pair(sc &first, sc &second, const u32 *__restrict__ seed8, u32 domain, u64 index) {
     u64 st[25];
     prf_state(st, seed8, domain, index);

@@ -139,23 +139,33 @@ __device__ __forceinline__ void msm_for_each_digit(const u32 s_in[8], u32 c, u32
 // nonzero_count (zero before the launch) receives the number of terms whose scalar is not zero: what the accumulation really works on
 // once terms that share a point have been merged into one
 __global__ void __launch_bounds__(256) k_msm_digits(const u32 *__restrict__ scalars, u64 n, msm_plan p, unsigned short *__restrict__ digits, u32 *__restrict__ big_count,
-                                                    u32 *__restrict__ nonzero_count) {
+                                                    u32 *__restrict__ block_nonzero /*one word per workgroup, or null*/) {
     wave_priority_high();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) big_count[0] = 0;                       // the merge stage's list of oversized buckets starts empty
     u32 s[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) s[k] = i < n ? scalars[8 * i + k] : 0u;
-    {
-        const bool nonzero = (s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) != 0;
-        const unsigned long long mask = __ballot(nonzero);
-        if ((threadIdx.x & 63) == 0 && mask) atomicAdd(nonzero_count, (u32)__popcll(mask));
+    if (block_nonzero) {                                // (statistics only; a count per workgroup, no contended counter)
+        const int cnt = __syncthreads_count((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) != 0);
+        if (threadIdx.x == 0) block_nonzero[blockIdx.x] = (u32)cnt;
     }
     if (i >= n) return;
     msm_for_each_digit(s, p.c, p.W, [&](u32 w, int d) {
         u32 a = d < 0 ? (u32)(-d) : (u32)d;
         digits[(u64)w * n + i] = (unsigned short)(a | (d < 0 ? 0x8000u : 0u));
     });
+}
+// out[0] += the sum of n counts (one workgroup)
+__global__ void __launch_bounds__(1024) k_msm_count_sum(const u32 *__restrict__ counts, u32 n, u32 *__restrict__ out) {
+    __shared__ u32 part[16];
+    u32 acc = 0;
+    for (u32 i = threadIdx.x; i < n; i += 1024) acc += counts[i];
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int k = 0; k < 16; k++) t += part[k]; out[0] += t; }
 }
 static constexpr u32 SORT_UNROLL = 8;        // independent loads in flight per thread in the counting and scattering loops
 // workgroup (tile, window): counts of the tile's digits per bucket -> tile_hist[(w * tiles + tile) * B + b]
@@ -754,7 +764,7 @@ void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, 
 }
 
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user) {
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user, bool count_terms) {
 #define MARK(name) do { if (mark) { hipError_t e_ = mark(mark_user, name); if (e_ != hipSuccess) return e_; } } while (0)
     u64 n_buckets = (u64)p.W * p.B, sorted_cap = n * p.W ? n * p.W : 1, chunks = msm_chunks(n, p);
     // With a term -> point map, the sort's entries name the point record directly when the index fits the entry (31 bits, 24 in
@@ -768,7 +778,10 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     const u32 tiles = (u32)msm_sort_tiles(n, p), lds_bytes = p.B * 4;
     unsigned short *digits = (unsigned short *)ws.digits;
     MARK("msm_histogram");
-    hipLaunchKernelGGL(k_msm_digits, dim3(n ? grid_for(n, 256) : 1), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list, d_result + 10);
+    // with count_terms, the terms with a non-zero scalar are counted into d_result[10] (the chunk sums are free until the accumulation)
+    const u32 digit_blocks = n ? grid_for(n, 256) : 1;
+    hipLaunchKernelGGL(k_msm_digits, dim3(digit_blocks), dim3(256), 0, st, d_scalars, n, p, digits, ws.big_list, count_terms ? ws.chunk_sums : (u32 *)nullptr);
+    if (count_terms) hipLaunchKernelGGL(k_msm_count_sum, dim3(1), dim3(1024), 0, st, ws.chunk_sums, digit_blocks, d_result + 10);
     if (!p.fine_bits) {
         hipLaunchKernelGGL(k_msm_tile_hist, dim3(tiles, p.W), dim3(512), lds_bytes, st, digits, n, p, tiles, ws.tile_hist);
         hipLaunchKernelGGL(k_msm_tile_prefix, dim3(grid_for(n_buckets, 256)), dim3(256), 0, st, ws.tile_hist, p, tiles, ws.hist);

@@ -6,58 +6,66 @@
 namespace xhe {
 
 // ---- sigma proofs ----------------------------------------------------------------------------------
+// A proof is three equations over points.  The reference folds them with powers of a transcript challenge w and gives the
+// proof one random batch factor (src/proofs.rs:188-208, 336-358: eq0 + w eq1 + w^2 eq2, times the factor).  Here every
+// equation gets a random factor of its own, of at least 128 bits (b0, b1, b2, drawn from the call's seed, independent of the proof): the
+// batch sum vanishes for all factors iff every equation holds, which is what the folded form establishes too (up to the same
+// negligible probability), and the commitments Y_0, Y_1, Y_2 - three of a proof's seven or eight terms - keep scalars of that
+// width, about half the digits of a full one in the bucket sort and the accumulation (the width: sigma_weight_bits).  The challenge w is still derived (the transcript
+// state goes on through it to the next proof); it is just not a factor.
 // gh[2p], gh[2p+1]: this proof's contributions to the scalars of G and H (Montgomery limbs)
 __device__ __forceinline__ void sigma_cm_terms(u32 i, const u8 *__restrict__ bytes, const dev_cm *__restrict__ cms, const dev_tx *__restrict__ txs,
                                                const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
-                                               u32 *__restrict__ term_point, u32 *__restrict__ gh) {
+                                               u32 *__restrict__ term_point, u32 *__restrict__ gh, u32 weight_bits) {
     const dev_cm c = cms[i];
     const dev_tx d = txs[c.tx];
     const u8 *p = bytes + c.off;
-    sc ch_c = load_scalar_words(chal + 8ull * (d.chal_off + 2 * c.idx)), ch_w = load_scalar_words(chal + 8ull * (d.chal_off + 2 * c.idx + 1));
+    sc ch_c = load_scalar_words(chal + 8ull * (d.chal_off + 2 * c.idx));
     sc z_s = load_scalar_bytes(p + 160), z_x = load_scalar_bytes(p + 192), z_r = load_scalar_bytes(p + 224);
-    sc bf = prf_scalar_128(seed, 1, i);
-    sc ww = sc_mul(ch_w, ch_w);
-    sc w_bf = sc_mul(ch_w, bf), ww_bf = sc_mul(ww, bf);
-    sc neg_bf = sc_neg(bf), neg_w_bf = sc_neg(w_bf), neg_ww_bf = sc_neg(ww_bf);
+    sc b0, b1, b2;
+    prf_scalar_x3(b0, b1, b2, seed, 1, i, weight_bits);
+    sc neg_b0 = sc_neg(b0), neg_b1 = sc_neg(b1), neg_b2 = sc_neg(b2);
     u32 *s = scalars + 8ull * c.term_off;
     u32 *tp = term_point + c.term_off;
-    store_scalar_words(s, sc_mul(z_s, bf));                  tp[0] = d.src_pt;          // z_s * P_source
-    store_scalar_words(s + 8, neg_bf);                        tp[1] = c.pt + 1;          // -Y_0
-    store_scalar_words(s + 16, sc_mul(w_bf, z_s));            tp[2] = c.src_ct_pt + 1;   // w z_s * D_source
-    store_scalar_words(s + 24, sc_mul(neg_w_bf, ch_c));       tp[3] = c.src_ct_pt;       // -w c * C_source
-    store_scalar_words(s + 32, neg_w_bf);                     tp[4] = c.pt + 2;          // -w * Y_1
-    store_scalar_words(s + 40, sc_mul(neg_ww_bf, ch_c));      tp[5] = c.pt;              // -ww c * C_destination
-    store_scalar_words(s + 48, neg_ww_bf);                    tp[6] = c.pt + 3;          // -ww * Y_2
-    // G: (w + ww) z_x bf ; H: (-c + ww z_r) bf
-    sc g = sc_mul(sc_add(w_bf, ww_bf), z_x);
-    sc h = sc_add(sc_mul(neg_bf, ch_c), sc_mul(ww_bf, z_r));
+    // eq0: z_s P_source - c H - Y_0        eq1: z_x G + z_s D_source - c C_source - Y_1        eq2: z_x G + z_r H - c C_destination - Y_2
+    store_scalar_words(s, sc_mul(z_s, b0));                   tp[0] = d.src_pt;          // b0 z_s * P_source
+    store_scalar_words(s + 8, neg_b0);                        tp[1] = c.pt + 1;          // -b0 * Y_0
+    store_scalar_words(s + 16, sc_mul(b1, z_s));              tp[2] = c.src_ct_pt + 1;   // b1 z_s * D_source
+    store_scalar_words(s + 24, sc_mul(neg_b1, ch_c));         tp[3] = c.src_ct_pt;       // -b1 c * C_source
+    store_scalar_words(s + 32, neg_b1);                       tp[4] = c.pt + 2;          // -b1 * Y_1
+    store_scalar_words(s + 40, sc_mul(neg_b2, ch_c));         tp[5] = c.pt;              // -b2 c * C_destination
+    store_scalar_words(s + 48, neg_b2);                       tp[6] = c.pt + 3;          // -b2 * Y_2
+    // G: (b1 + b2) z_x ; H: -b0 c + b2 z_r
+    sc g = sc_mul(sc_add(b1, b2), z_x);
+    sc h = sc_add(sc_mul(neg_b0, ch_c), sc_mul(b2, z_r));
     store_sc_limbs(gh + 18ull * i, sc_norm(g));
     store_sc_limbs(gh + 18ull * i + 9, sc_norm(h));
 }
 __device__ __forceinline__ void sigma_xf_terms(u32 i, const u8 *__restrict__ bytes, const dev_xfer *__restrict__ xfers, const dev_tx *__restrict__ txs,
                                                const u32 *__restrict__ chal, const u32 *__restrict__ seed, u32 *__restrict__ scalars,
-                                               u32 *__restrict__ term_point, u32 *__restrict__ gh) {
+                                               u32 *__restrict__ term_point, u32 *__restrict__ gh, u32 weight_bits) {
     const dev_xfer x = xfers[i];
     const dev_tx d = txs[x.tx];
     const u8 *pr = bytes + x.proof_off;
     u32 cbase = d.chal_off + 2 * d.n_commitments + 2 * x.idx;
-    sc ch_c = load_scalar_words(chal + 8ull * cbase), ch_w = load_scalar_words(chal + 8ull * (cbase + 1));
+    sc ch_c = load_scalar_words(chal + 8ull * cbase);
     sc z_r = load_scalar_bytes(pr + 96), z_x = load_scalar_bytes(pr + 128);
-    sc bf = prf_scalar_128(seed, 2, i);
-    sc w_bf = sc_mul(ch_w, bf), ww_bf = sc_mul(sc_mul(ch_w, ch_w), bf);
-    sc neg_bf = sc_neg(bf), neg_w_bf = sc_neg(w_bf), neg_ww_bf = sc_neg(ww_bf);
+    sc b0, b1, b2;
+    prf_scalar_x3(b0, b1, b2, seed, 2, i, weight_bits);
+    sc neg_b0 = sc_neg(b0), neg_b1 = sc_neg(b1), neg_b2 = sc_neg(b2);
     u32 *s = scalars + 8ull * x.term_off;
     u32 *tp = term_point + x.term_off;
-    store_scalar_words(s, sc_mul(neg_bf, ch_c));              tp[0] = x.pt;              // -c * C
-    store_scalar_words(s + 8, neg_bf);                        tp[1] = x.pt + 3;          // -Y_0
-    store_scalar_words(s + 16, sc_mul(w_bf, z_r));            tp[2] = x.dest_pt;         // w z_r * P_dest
-    store_scalar_words(s + 24, sc_mul(neg_w_bf, ch_c));       tp[3] = x.pt + 2;          // -w c * D_dest
-    store_scalar_words(s + 32, neg_w_bf);                     tp[4] = x.pt + 4;          // -w * Y_1
-    store_scalar_words(s + 40, sc_mul(ww_bf, z_r));           tp[5] = d.src_pt;          // ww z_r * P_source
-    store_scalar_words(s + 48, sc_mul(neg_ww_bf, ch_c));      tp[6] = x.pt + 1;          // -ww c * D_source
-    store_scalar_words(s + 56, neg_ww_bf);                    tp[7] = x.pt + 5;          // -ww * Y_2
-    store_sc_limbs(gh + 18ull * i, sc_norm(sc_mul(z_x, bf)));
-    store_sc_limbs(gh + 18ull * i + 9, sc_norm(sc_mul(z_r, bf)));
+    // eq0: z_r H + z_x G - c C - Y_0        eq1: z_r P_dest - c D_dest - Y_1        eq2: z_r P_source - c D_source - Y_2
+    store_scalar_words(s, sc_mul(neg_b0, ch_c));              tp[0] = x.pt;              // -b0 c * C
+    store_scalar_words(s + 8, neg_b0);                        tp[1] = x.pt + 3;          // -b0 * Y_0
+    store_scalar_words(s + 16, sc_mul(b1, z_r));              tp[2] = x.dest_pt;         // b1 z_r * P_dest
+    store_scalar_words(s + 24, sc_mul(neg_b1, ch_c));         tp[3] = x.pt + 2;          // -b1 c * D_dest
+    store_scalar_words(s + 32, neg_b1);                       tp[4] = x.pt + 4;          // -b1 * Y_1
+    store_scalar_words(s + 40, sc_mul(b2, z_r));              tp[5] = d.src_pt;          // b2 z_r * P_source
+    store_scalar_words(s + 48, sc_mul(neg_b2, ch_c));         tp[6] = x.pt + 1;          // -b2 c * D_source
+    store_scalar_words(s + 56, neg_b2);                       tp[7] = x.pt + 5;          // -b2 * Y_2
+    store_sc_limbs(gh + 18ull * i, sc_norm(sc_mul(z_x, b0)));
+    store_sc_limbs(gh + 18ull * i + 9, sc_norm(sc_mul(z_r, b0)));
 }
 
 // sum of n scalars (Montgomery limbs, stride words apart) per residue class j = 0..classes-1:
@@ -214,10 +222,10 @@ __global__ void __launch_bounds__(64, 2) k_proof_scalars(proof_scalar_args a) {
     u32 blk = blockIdx.x;
     if (blk < b_cm) {
         u32 i = blk * 64 + threadIdx.x;
-        if (i < a.n_cm) sigma_cm_terms(i, a.bytes, a.cms, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh);
+        if (i < a.n_cm) sigma_cm_terms(i, a.bytes, a.cms, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh, a.weight_bits);
     } else if (blk < b_cm + b_xf) {
         u32 i = (blk - b_cm) * 64 + threadIdx.x;
-        if (i < a.n_xf) sigma_xf_terms(i, a.bytes, a.xfers, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh + 18ull * a.n_cm);
+        if (i < a.n_xf) sigma_xf_terms(i, a.bytes, a.xfers, a.txs, a.chal, a.seed, a.scalars, a.term_point, a.gh + 18ull * a.n_cm, a.weight_bits);
     } else {
         u32 r = blk - b_cm - b_xf;                     // even workgroups: side 0, odd: side 1 of the same 64 transactions
         u32 i = (r >> 1) * 64 + threadIdx.x;

@@ -26,7 +26,7 @@ struct msm_ws_bytes { u64 hist, offsets, tile_hist, sorted, buckets, digits, chu
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p);
 typedef hipError_t (*msm_mark_fn)(void *user, const char *name);
 // result: identity flag at d_result[8]; with want_encoding also the 8 words of the sum's encoding at d_result[0..8); d_result[9] = sorted
-// entries the accumulation went through, d_result[10] += terms with a non-zero scalar (the caller clears d_result before the launch)
+// entries the accumulation went through, with count_terms d_result[10] += terms with a non-zero scalar (the caller clears d_result before the launch)
 // What the multiscalar multiplication waits for on other streams: the sort of the scalars needs none of it.
 struct msm_deps {
     hipEvent_t points_ready[2] = {nullptr, nullptr};   // waited for before the first point is gathered
@@ -34,7 +34,7 @@ struct msm_deps {
     hipEvent_t extra_ready = nullptr;                   // ... valid once this has fired
 };
 hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, const u32 *d_term_point, u64 n_points, u64 n, const msm_plan &p,
-                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user);
+                      const msm_ws &ws, u32 *d_result, bool want_encoding, const msm_deps &deps, msm_mark_fn mark, void *mark_user, bool count_terms = false);
 // Sum of scalars[j] * P_j over the static generators B, H, G_vec[nm_cap], H_vec[nm_cap] from 32 x 256 fixed-base tables laid out
 // for capacity table_cap: partial sums per workgroup, then one wave.  partials: ceil(32 (2 + 2 nm_cap) / 256) XYZT records; out: one.
 void launch_static_eval(hipStream_t st, const u32 *gen_tab, const u32 *scalars, u32 nm_cap, u32 table_cap, u32 *partials, u32 *out);
@@ -100,7 +100,12 @@ static_assert(RPC_E + 16 == RPC_SCALARS, "context layout");
 struct proof_scalar_args {
     const u8 *bytes; const dev_tx *txs; const dev_cm *cms; const dev_xfer *xfers; u32 n_cm, n_xf, n_txs;
     const u32 *chal, *seed; u32 *scalars, *term_point, *rp_ctx, *gh, *rp_err;
+    u32 weight_bits;       // width of the sigma equations' random factors: sigma_weight_bits(window width of the check they enter)
 };
+// A random factor fills a whole number of the bucket sort's windows, less the top bit: its digits are then spread evenly over
+// the buckets of every window it reaches and the signed recoding never carries out of its top window (a narrower top window
+// would put a third of all terms into a few buckets of one window, a carry half of them into one bucket).  At least 128 bits.
+static inline u32 sigma_weight_bits(u32 c) { return c * ((129 + c - 1) / c) - 1; }
 void launch_proof_scalars(hipStream_t st, const proof_scalar_args &a);
 // Terms that share a point: pairs (kept term, absorbed term), and runs of terms (run_off[n_runs + 1] into run_terms) whose
 // first term takes the run's sum; absorbed scalars become zero

@@ -120,7 +120,7 @@ static int32_t msm_device(xhe_ctx *ctx, const u32 *d_scalars, const u32 *d_niels
     HIPCHK(ctx, ws.coarse.reserve(need.coarse));
     msm_ws w{ws.hist.as<u32>(), ws.offsets.as<u32>(), ws.tile_hist.as<u32>(), ws.sorted.as<u32>(), ws.buckets.as<u32>(), ws.digits.as<u32>(), ws.chunk_sums.as<u32>(),
              ws.big_list.as<u32>(), ws.segs.as<u32>(), ws.wins.as<u32>(), ws.tmp.as<u32>(), ws.coarse.as<u32>()};
-    HIPCHK(ctx, msm_launch(stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, (timing || acc_events) ? timer_mark : nullptr, &target));
+    HIPCHK(ctx, msm_launch(stream, d_scalars, d_niels, d_term_point, n_points, n, p, w, d_result, want_encoding, deps, (timing || acc_events) ? timer_mark : nullptr, &target, acc_events != nullptr));
     return 0;
 }
 
@@ -809,12 +809,14 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
         // Shares of the record bytes, at least one transaction each.  The first part is smaller than the others (half their size;
         // XHE_SPLIT_FIRST = its share in per cent of theirs): the device idles while the host parses it.
         const u64 rec_bytes = offsets[n_txs];
-        u64 first_pct = 50;
+        u64 first_pct = 50, second_pct = 100;
         if (const char *e = getenv("XHE_SPLIT_FIRST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) first_pct = v; }
-        const u64 total_weight = first_pct + 100ull * (n_parts - 1);
+        if (const char *e = getenv("XHE_SPLIT_SECOND")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) second_pct = v; }
+        std::vector<u64> upto(n_parts + 1, 0);                      // weight of the parts in front of part k
+        for (u32 k = 0; k < n_parts; k++) upto[k + 1] = upto[k] + (k == 0 ? first_pct : (k == 1 ? second_pct : 100));
         u64 lo = 0;
         for (u32 k = 0; k < n_parts; k++) {
-            const u64 cut = (u64)((unsigned __int128)rec_bytes * (first_pct + 100ull * k) / total_weight);
+            const u64 cut = (u64)((unsigned __int128)rec_bytes * upto[k + 1] / upto[n_parts]);
             u64 hi = k + 1 == n_parts ? n_txs : (u64)(std::lower_bound(offsets, offsets + n_txs, cut) - offsets);
             hi = std::max(hi, lo + 1); hi = std::min(hi, n_txs - (n_parts - 1 - k));
             parts[k].lo = lo; parts[k].hi = hi;
@@ -1359,7 +1361,9 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     // main: proof scalars (sigma terms, range-proof terms, per-transaction range-proof context)
     HIPCHK(ctx, tm.mark("proof_scalars", st));
     {
-        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
+        const bool tables = ctx->gen_tab_cap != 0 && hb.nm_cap <= ctx->gen_tab_cap;
+        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err,
+                             sigma_weight_bits(msm_make_plan(tables ? hb.static_term_off : hb.n_terms).c)};
         launch_proof_scalars(st, pa);
         // terms on one point become one term: a value commitment's sigma and range-proof terms, every term on an account's key
         const char *merge_env = getenv("XHE_MERGE_TERMS");
@@ -1463,7 +1467,8 @@ static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verd
     // (verify.rs:500-514) with the sigma-only multiscalar check.
     {
         // the merged scalars mix sigma-proof and range-proof terms: the sigma-only check runs on the scalars as the proofs give them
-        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err};
+        proof_scalar_args pa{bytes, txs, cms, xfers, n_cm, n_xf, n_txs, chal, sd, scalars, term_point, B->rp_ctx.as<u32>(), gh, rp_err,
+                             sigma_weight_bits(msm_make_plan((u64)hb.sigma_terms + 2).c)};
         launch_proof_scalars(st, pa);
         u32 n_sig_terms = hb.sigma_terms;
         dev_buf s2, tp2, r2;
