@@ -241,6 +241,32 @@ typedef struct xhe_msm_stats { uint64_t launches; uint64_t entries; uint64_t ter
 int32_t xhe_msm_stats_enable(xhe_ctx *ctx, int32_t on);
 int32_t xhe_msm_stats_read(xhe_ctx *ctx, xhe_msm_stats *out, int32_t reset);
 
+/* ---- Balance decoding (ECDLPInstance::decode, src/elgamal.rs:68-92) ----------------------------------------
+ * The reference decodes a decrypted point m*G into the integer m with the ecdlp module of its curve25519-dalek fork and that
+ * module's pre-computed table files; module and file format are outside the reference's sources, so the tables here are this
+ * library's own (built on the GPU, never written to disk) and only the contract is the reference's: the integer, or none.
+ *
+ * xhe_ecdlp_table_create builds the baby-step table for 2^table_bits steps (8..30; 2^(table_bits+4) bytes of device memory:
+ * 256 MiB at 24, 4 GiB at 28, 16 GiB at 30) - the counterpart of loading an ECDLPTablesFileView.  A table belongs to its context
+ * and, like it, serves one call at a time.
+ *
+ * xhe_ecdlp_decode: points32 = n Ristretto encodings (what ECDLPInstance holds, src/elgamal.rs:68).  amounts[i] = m with
+ * m*G = point i and 0 <= m < 2^max_bits, or -1 when there is none in that range (the reference's None) or the encoding is
+ * invalid (status[i] = 1 then; status may be NULL).  max_bits 1..62 and at most table_bits + 25.  n <= 2^24.
+ * xhe_elgamal_decrypt_decode: cts64 = n ciphertexts (commitment || handle) under one secret key; the point is C - s*D
+ * (ElGamalSecretKey::decrypt, src/elgamal.rs:140-145), decoded as above.  ECDLPArguments' range start and progress callback
+ * have no counterpart: the range starts at 0 and a call is a few milliseconds. */
+typedef struct xhe_ecdlp_table xhe_ecdlp_table;
+int32_t xhe_ecdlp_table_create(xhe_ctx *ctx, uint32_t table_bits, xhe_ecdlp_table **out);
+void xhe_ecdlp_table_free(xhe_ecdlp_table *table);
+int32_t xhe_ecdlp_decode(xhe_ecdlp_table *table, const uint8_t *points32, uint64_t n, uint32_t max_bits, int64_t *amounts, uint8_t *status);
+int32_t xhe_elgamal_decrypt_decode(xhe_ecdlp_table *table, const uint8_t secret32[32], const uint8_t *cts64, uint64_t n, uint32_t max_bits, int64_t *amounts,
+                                   uint8_t *status);
+/* The last decode call on this table: instances, giant steps walked (one hash-table look-up each), GPU time of the walk from a
+ * pair of HIP events on its stream, lanes used.  No counterpart in the reference (measurement). */
+typedef struct xhe_ecdlp_stats { uint64_t instances; uint64_t steps; double walk_ms; uint64_t lanes; } xhe_ecdlp_stats;
+int32_t xhe_ecdlp_last_stats(const xhe_ecdlp_table *table, xhe_ecdlp_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ int32_t xhe_keygen(const uint8_t secret32[32], uint8_t pub32[32]);
 int32_t xhe_keygen_from_seed(const uint8_t seed32[32], uint8_t secret32[32], uint8_t pub32[32]);
 int32_t xhe_encrypt(const uint8_t pub32[32], uint64_t amount, const uint8_t seed32[32], uint8_t ct64[64]);
 int32_t xhe_ct_decrypts_to(const uint8_t secret32[32], const uint8_t ct64[64], uint64_t amount);
+/* ElGamalSecretKey::decrypt (src/elgamal.rs:140-145): out32 = the encoding of amount*G = C - s*D; -1 when a point does not decode */
+int32_t xhe_decrypt_to_point(const uint8_t secret32[32], const uint8_t ct64[64], uint8_t out32[32]);
 int32_t xhe_sign(const uint8_t secret32[32], const uint8_t *msg, uint64_t n, const uint8_t seed32[32], uint8_t sig64[64]);
 int32_t xhe_signature_verify_host(const uint8_t sig64[64], const uint8_t *msg, uint64_t n, const uint8_t pub32[32]);
 

@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include <time.h>
 #include <thread>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include "xo_tx.h"
 
 namespace xo {
@@ -207,6 +210,52 @@ int32_t xo_apply_batch(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     for (uint64_t i = 0; i < n; i++) if (!apply_without_verify(txs[i], st, (int64_t)i)) return -2;
     if (out) st.store(*in, *out);
     return 0;
+}
+
+// ElGamalSecretKey::decrypt (/root/reference/src/elgamal.rs:140-145): the encoding of C - s * D; -1 when a point does not decode
+int32_t xo_decrypt_point(const uint8_t secret32[32], const uint8_t ct64[64], uint8_t out32[32]) {
+    warm();
+    ge c, d;
+    if (!ristretto_decode(c, ct64) || !ristretto_decode(d, ct64 + 32)) return -1;
+    ristretto_encode(out32, ge_sub(c, ge_scalarmul(sc_from_bytes_mod_order(secret32), d)));
+    return 0;
+}
+// ECDLPInstance::decode (/root/reference/src/elgamal.rs:68-92) restated as the plainest baby-step/giant-step: the m in
+// [0, 2^max_bits) with m * G = point, or -1.  The reference's own decoder (the ecdlp module of its curve25519-dalek fork) is not
+// among its sources; what is restated is its contract.  Keys are canonical encodings, so every look-up is exact.
+// max_bits <= 40 (2^16 baby steps, 2^(max_bits-16) giant steps of one encoding each).
+int64_t xo_ecdlp_decode(const uint8_t point32[32], uint32_t max_bits) {
+    warm();
+    if (max_bits < 1 || max_bits > 40) return -2;
+    ge p;
+    if (!ristretto_decode(p, point32)) return -1;
+    static std::mutex mu;
+    static std::unordered_map<std::string, uint32_t> baby;
+    static const uint32_t B = 16;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (baby.empty()) {
+            ge q = ge_identity();
+            for (uint32_t j = 0; j < (1u << B); j++) {
+                u8 e[32]; ristretto_encode(e, q);
+                baby.emplace(std::string((const char *)e, 32), j);
+                q = ge_add(q, ge_basepoint());
+            }
+        }
+    }
+    const ge stride = ge_neg(ge_scalarmul(sc_from_u64(1ull << B), ge_basepoint()));
+    const uint64_t giant = max_bits > B ? 1ull << (max_bits - B) : 1;
+    ge q = p;
+    for (uint64_t i = 0; i < giant; i++) {
+        u8 e[32]; ristretto_encode(e, q);
+        auto it = baby.find(std::string((const char *)e, 32));
+        if (it != baby.end()) {
+            const uint64_t m = (i << B) + it->second;
+            return (m >> max_bits) ? -1 : (int64_t)m;
+        }
+        q = ge_add(q, stride);
+    }
+    return -1;
 }
 
 // The Fiat-Shamir challenges of one transaction in transcript order, for comparing the device

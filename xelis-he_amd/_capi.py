@@ -17,6 +17,10 @@ def lib_path():
 _lib = None
 
 
+class EcdlpStats(ctypes.Structure):
+    _fields_ = [("instances", ctypes.c_uint64), ("steps", ctypes.c_uint64), ("walk_ms", ctypes.c_double), ("lanes", ctypes.c_uint64)]
+
+
 def load_library():
     """Loads libxhe.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
     global _lib
@@ -44,6 +48,17 @@ def load_library():
     lib.xhe_last_stage_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
     lib.xhe_set_stage_timing.restype = ctypes.c_int32
     lib.xhe_set_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    lib.xhe_ecdlp_table_create.restype = ctypes.c_int32
+    lib.xhe_ecdlp_table_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.xhe_ecdlp_table_free.restype = None
+    lib.xhe_ecdlp_table_free.argtypes = [ctypes.c_void_p]
+    lib.xhe_ecdlp_decode.restype = ctypes.c_int32
+    lib.xhe_ecdlp_decode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, i64p, u8p]
+    lib.xhe_elgamal_decrypt_decode.restype = ctypes.c_int32
+    lib.xhe_elgamal_decrypt_decode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, i64p, u8p]
+    lib.xhe_ecdlp_last_stats.restype = ctypes.c_int32
+    lib.xhe_ecdlp_last_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(EcdlpStats)]
     _lib = lib
     return lib
 
@@ -110,3 +125,49 @@ class Engine:
         ms = (ctypes.c_float * 64)()
         n = self.lib.xhe_last_stage_times(self.ctx, names, ms, 64)
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+
+class EcdlpTable:
+    """xhe_ecdlp_table: the baby-step table of the balance decoder on one GPU (the place of ecdlp::ECDLPTablesFileView,
+    src/elgamal.rs:79).  2^(table_bits + 4) bytes of device memory."""
+
+    def __init__(self, engine: Engine, table_bits=24):
+        self.engine, self.lib, self.table_bits = engine, engine.lib, int(table_bits)
+        h = ctypes.c_void_p()
+        engine._check(self.lib.xhe_ecdlp_table_create(engine.ctx, self.table_bits, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.xhe_ecdlp_table_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _out(self, n):
+        return (ctypes.c_int64 * max(n, 1))(), (ctypes.c_uint8 * max(n, 1))()
+
+    def decode(self, points32: bytes, max_bits: int):
+        """ECDLPInstance::decode over a batch of encodings: a list of amounts, None where the point is no m*G with m < 2^max_bits."""
+        assert len(points32) % 32 == 0
+        n = len(points32) // 32
+        amounts, status = self._out(n)
+        self.engine._check(self.lib.xhe_ecdlp_decode(self.handle, points32, n, int(max_bits), amounts, status))
+        return [None if amounts[i] < 0 else int(amounts[i]) for i in range(n)]
+
+    def decrypt_decode(self, secret32: bytes, cts64: bytes, max_bits: int):
+        """ElGamalSecretKey::decrypt followed by decode for ciphertexts under one key."""
+        assert len(cts64) % 64 == 0 and len(secret32) == 32
+        n = len(cts64) // 64
+        amounts, status = self._out(n)
+        self.engine._check(self.lib.xhe_elgamal_decrypt_decode(self.handle, secret32, cts64, n, int(max_bits), amounts, status))
+        return [None if amounts[i] < 0 else int(amounts[i]) for i in range(n)]
+
+    def last_stats(self):
+        st = EcdlpStats()
+        self.lib.xhe_ecdlp_last_stats(self.handle, ctypes.byref(st))
+        return {"instances": int(st.instances), "steps": int(st.steps), "walk_ms": float(st.walk_ms), "lanes": int(st.lanes)}

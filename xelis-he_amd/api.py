@@ -81,6 +81,14 @@ def _lib():
             lib.xhe_verify_batch.restype = ctypes.c_int32
             lib.xhe_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64,
                                              ctypes.POINTER(LedgerView), ctypes.POINTER(LedgerOut), ctypes.POINTER(Verdict), ctypes.c_char_p]
+        # 64-bit amounts: without declared argument types ctypes passes a Python int as a C int
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        lib.xhe_encrypt.restype = ctypes.c_int32
+        lib.xhe_encrypt.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, u8p]
+        lib.xhe_ct_decrypts_to.restype = ctypes.c_int32
+        lib.xhe_ct_decrypts_to.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64]
+        lib.xhe_decrypt_to_point.restype = ctypes.c_int32
+        lib.xhe_decrypt_to_point.argtypes = [ctypes.c_char_p, ctypes.c_char_p, u8p]
         lib.xhe_synth_transfers.restype = ctypes.c_void_p
         lib.xhe_synth_transfers.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32]
         lib.xhe_synth_transfers_gpu.restype = ctypes.c_void_p
@@ -129,6 +137,27 @@ class Keypair:
 
     def decrypts_to(self, ct: bytes, amount: int) -> bool:
         return _lib().xhe_ct_decrypts_to(self.secret, ct, amount) == 1
+
+    def decrypt(self, ct: bytes) -> "ECDLPInstance":
+        """ElGamalSecretKey::decrypt (src/elgamal.rs:140-145): the point amount*G, still to be decoded."""
+        out = (ctypes.c_uint8 * 32)()
+        if _lib().xhe_decrypt_to_point(self.secret, ct, out) != 0:
+            raise XheError("ciphertext does not decode")
+        return ECDLPInstance(bytes(out))
+
+
+class ECDLPInstance:
+    """src/elgamal.rs:68-92: a decrypted point; decode() finds the integer with the GPU's baby-step table."""
+
+    def __init__(self, point32: bytes):
+        self.point = bytes(point32)
+
+    def as_point(self) -> bytes:
+        return self.point
+
+    def decode(self, tables, max_bits=48):
+        """tables: xelis_he_amd.EcdlpTable.  The amount, or None (the reference's Option<i64>)."""
+        return tables.decode(self.point, max_bits)[0]
 
 
 class Account:

@@ -64,6 +64,12 @@ int32_t xhe_ct_decrypts_to(const uint8_t secret32[32], const uint8_t ct64[64], u
     ge pt = ge_sub(c.C, scalarmul(s, c.D));
     return ge_ristretto_eq(pt, mul_G(sc_from_u64(amount))) ? 1 : 0;
 }
+// ElGamalSecretKey::decrypt (elgamal.rs:140-145): the encoding of the point amount*G = C - s*D (what ECDLPInstance holds)
+int32_t xhe_decrypt_to_point(const uint8_t secret32[32], const uint8_t ct64[64], uint8_t out32[32]) {
+    ciphertext c; if (!ct_from_bytes(c, ct64)) return -1;
+    ristretto_encode(out32, ge_sub(c.C, scalarmul(sc_frombytes(secret32), c.D)));
+    return 0;
+}
 int32_t xhe_sign(const uint8_t secret32[32], const uint8_t *msg, uint64_t n, const uint8_t seed32[32], uint8_t sig64[64]) {
     keypair k = keypair::from_secret(sc_frombytes(secret32));
     drbg rng(seed32);

@@ -1,0 +1,494 @@
+// Balance decoding: the discrete logarithm m of a decrypted point m*G for m below 2^max_bits
+// (ECDLPInstance::decode, /root/reference/src/elgamal.rs:68-92; the point comes from ElGamalSecretKey::decrypt, :140-145).
+// The reference hands this to the ecdlp module of its curve25519-dalek fork (pre-computed table files); that module and its
+// table format are not part of the reference's sources, so what is reproduced here is the contract - the integer, or none -
+// with a table format of this library's own.
+//
+// Baby-step/giant-step laid out for a GPU with a large HBM:
+//   * every point is first multiplied by 4 (two doublings): a decoded Ristretto point is a representative up to 4-torsion,
+//     4*P is the same Edwards point for all representatives, and m*G = P  <=>  m*(4G) = 4P.  All arithmetic below is on
+//     plain affine Edwards points of the prime-order subgroup, base B4 = 4G.
+//   * baby table: an open-addressing hash table in HBM, 2^(b+1) slots of 8 bytes, holding (32 bits of y, j) for the affine
+//     y of j*B4, 0 <= j <= 2^b (+ a few more).  y(-Q) = y(Q), so one entry answers +j and -j.
+//   * giant steps: m = (2i+1) 2^b + delta, -2^b <= delta < 2^b.  Q_i = 4P - (2i+1) 2^b B4 = (4P - 2^b B4) + (-i S), S = 2^(b+1) B4,
+//     is looked up for i = 0 .. 2^(max_bits-b-1) - 1.  The points -i*S are a table of affine points shared by all instances.
+//   * a step is one affine addition of a table point to the instance's point, of which only y is needed:
+//       y3 = (y1 y2 + x1 x2) / (1 - d x1 x2 y1 y2)        (complete on this curve: the denominator is never zero)
+//     The denominators of K consecutive steps are inverted together (running products stored in a scratch array, one
+//     inversion per K steps, second pass backwards): 8 field products per step + 265/K for the inversion.
+//   * a hit on the 32 stored bits is a candidate; candidates are confirmed by computing m*B4 (rare, separate small kernel).
+// Work is spread as (instance, segment of the giant-step range) per lane; lanes of a wavefront either share the table point
+// (many instances) or share the instance (few instances, many segments).
+#include <algorithm>
+#include <memory>
+#include <vector>
+#include "xhe_ctx.h"
+#include "xhe_dev_common.h"
+
+using namespace xhe;
+
+namespace xhe {
+
+static constexpr u32 EC_ENTRY_WORDS = 32;                  // x[10], y[10], c[10] raw limbs, 2 unused: 128 bytes
+static constexpr unsigned long long EC_EMPTY = ~0ull;
+static constexpr u32 EC_MAX_PROBE = 64;
+static constexpr u32 EC_CHUNK = 128;                       // steps per shared inversion (and per lane's share of the scratch array)
+
+__device__ __forceinline__ fe ec_load_fe(const u32 *p) { fe r; for (int i = 0; i < 10; i++) r.v[i] = p[i]; return r; }
+__device__ __forceinline__ void ec_store_fe(u32 *p, const fe &a) { for (int i = 0; i < 10; i++) p[i] = a.v[i]; }
+// an entry through 16-byte loads (entries are 128-byte aligned): where every lane reads an entry of its own, the number of
+// load instructions, each touching 64 lines, is what the address unit is busy with
+__device__ __forceinline__ void ec_load_c(const u32 *e, fe &c) {
+    const uint4 *q = (const uint4 *)e;
+    const uint4 a = q[5], b = q[6], d = q[7];
+    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w; c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w; c.v[8] = d.x; c.v[9] = d.y;
+}
+__device__ __forceinline__ void ec_load_entry(const u32 *e, fe &x, fe &y, fe &c) {
+    const uint4 *q = (const uint4 *)e;
+    const uint4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+    x.v[0] = r0.x; x.v[1] = r0.y; x.v[2] = r0.z; x.v[3] = r0.w; x.v[4] = r1.x; x.v[5] = r1.y; x.v[6] = r1.z; x.v[7] = r1.w; x.v[8] = r2.x; x.v[9] = r2.y;
+    y.v[0] = r2.z; y.v[1] = r2.w; y.v[2] = r3.x; y.v[3] = r3.y; y.v[4] = r3.z; y.v[5] = r3.w; y.v[6] = r4.x; y.v[7] = r4.y; y.v[8] = r4.z; y.v[9] = r4.w;
+    ec_load_c(e, c);
+}
+// scratch element k of this lane: word w at ((k * 10 + w) * n_lanes + lane), so a wavefront's accesses are contiguous
+__device__ __forceinline__ fe ec_scratch_load(const u32 *s, u64 n_lanes, u64 lane, u32 k) {
+    fe r;
+#pragma unroll
+    for (int w = 0; w < 10; w++) r.v[w] = s[((u64)k * 10 + w) * n_lanes + lane];
+    return r;
+}
+__device__ __forceinline__ void ec_scratch_store(u32 *s, u64 n_lanes, u64 lane, u32 k, const fe &a) {
+#pragma unroll
+    for (int w = 0; w < 10; w++) s[((u64)k * 10 + w) * n_lanes + lane] = a.v[w];
+}
+
+__device__ ge ec_mul_u64(const ge &base, u64 m) {
+    ge r = ge_identity();
+    bool started = false;
+    for (int bit = 63; bit >= 0; bit--) {
+        if (started) r = ge_double(r);
+        if ((m >> bit) & 1) { r = started ? ge_add(r, base) : base; started = true; }
+    }
+    return r;
+}
+__device__ ge ec_mul_words(const ge &base, const u32 k[8]) {
+    ge r = ge_identity();
+    bool started = false;
+    for (int bit = 255; bit >= 0; bit--) {
+        if (started) r = ge_double(r);
+        if ((k[bit >> 5] >> (bit & 31)) & 1) { r = started ? ge_add(r, base) : base; started = true; }
+    }
+    return r;
+}
+
+// multiples (first + t) * base for t < count as projective X, Y, Z (raw limbs) in entries of EC_ENTRY_WORDS words
+__global__ void __launch_bounds__(64) k_ec_multiples(const u32 *__restrict__ base_xyzt, u64 first, u64 count, u32 per_lane, u32 *__restrict__ out) {
+    const u64 lane = (u64)blockIdx.x * 64 + threadIdx.x;
+    const u64 lo = lane * per_lane;
+    if (lo >= count) return;
+    const u64 hi = lo + per_lane < count ? lo + per_lane : count;
+    const ge base = ge_load(base_xyzt);
+    ge p = ec_mul_u64(base, first + lo);
+    for (u64 t = lo; t < hi; t++) {
+        u32 *e = out + EC_ENTRY_WORDS * t;
+        ec_store_fe(e, p.X); ec_store_fe(e + 10, p.Y); ec_store_fe(e + 20, p.Z);
+        p = ge_add(p, base);
+    }
+}
+// in place: projective entries -> affine x, y and c = x y (times d when times_d), x and c negated when negate
+__global__ void __launch_bounds__(64) k_ec_normalize(u32 *__restrict__ entries, u64 count, u32 per_lane, u32 *__restrict__ scratch, u64 n_lanes, u32 negate, u32 times_d) {
+    const u64 lane = (u64)blockIdx.x * 64 + threadIdx.x;
+    const u64 lo = lane * per_lane;
+    if (lo >= count) return;
+    const u32 n = (u32)((lo + per_lane < count ? lo + per_lane : count) - lo);
+    fe run = fe_one();
+    for (u32 k = 0; k < n; k++) {
+        run = fe_mul(run, ec_load_fe(entries + EC_ENTRY_WORDS * (lo + k) + 20));
+        ec_scratch_store(scratch, n_lanes, lane, k, run);
+    }
+    fe inv = fe_invert(run);
+    const fe d = fe_c_d();
+    for (u32 k = n; k-- > 0;) {
+        u32 *e = entries + EC_ENTRY_WORDS * (lo + k);
+        const fe X = ec_load_fe(e), Y = ec_load_fe(e + 10), Z = ec_load_fe(e + 20);
+        const fe zinv = k ? fe_mul(inv, ec_scratch_load(scratch, n_lanes, lane, k - 1)) : inv;
+        inv = fe_mul(inv, Z);
+        fe x = fe_mul(X, zinv), y = fe_mul(Y, zinv);
+        fe c = fe_mul(x, y);
+        if (times_d) c = fe_mul(c, d);
+        if (negate) { x = fe_negate(x); c = fe_negate(c); }
+        ec_store_fe(e, x); ec_store_fe(e + 10, y); ec_store_fe(e + 20, c);
+    }
+}
+
+struct ec_bsgs_args {
+    const u32 *inst;           // per instance: x, y, x*y (EC_ENTRY_WORDS words)
+    u64 n_items;               // instances << segs_log2: this launch's items
+    u64 n_inst;
+    u32 segs_log2;             // an item is (instance, segment seg_first + item mod 2^segs_log2)
+    u64 seg_first;
+    const u32 *gt;             // table points: x, y, d*x*y
+    u64 steps_per_item;        // an item's range of table points: [seg * steps_per_item, (seg + 1) * steps_per_item)
+    u64 round_first, round_steps;   // the part of that range this launch walks: [round_first, round_first + round_steps)
+    u32 K;                     // steps per shared inversion
+    u32 *scratch; u64 n_lanes; // K * 10 words per lane; n_lanes = the whole grid
+    unsigned long long *slots; u32 slot_bits;
+    // look-up only
+    u32 *cand; u32 cand_cap; u32 *cand_count; const unsigned long long *amounts; unsigned long long *steps_done;
+};
+
+__device__ __forceinline__ void ec_key(const fe &y, u64 &slot, u32 &fp, u32 slot_bits) {
+    u32 w[8]; fe_pack(w, y);
+    const u64 h = ((u64)w[1] << 32 | w[0]) * 0x9e3779b97f4a7c15ull;
+    slot = h >> (64 - slot_bits);
+    fp = w[2] ^ (w[3] * 0x85ebca6bu);
+}
+
+// MODE 0: insert (fp, j) with j = item * steps_per_item + step.  MODE 1: look up, append candidates (instance, step, j).
+// A chunk of K steps goes in three passes: forward (running products of the denominators into the scratch array), backward
+// (the y of every sum; its table slot and check bits replace the running product in the scratch array), then the table:
+// eight independent accesses in flight per lane, which is what hides the latency of a random read in a table of gigabytes.
+template <int MODE>
+__device__ __forceinline__ void ec_bsgs_body(const ec_bsgs_args &a) {
+    // a lane keeps its place in the scratch array and takes items lane, lane + n_lanes, ...: the grid is what the chip holds at
+    // once, so no wavefront runs in a thin last round
+    const u64 lane = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 done = 0;
+    for (u64 item = lane; item < a.n_items; item += a.n_lanes) {
+        // neighbouring lanes are segments of one instance: once it is found, whole wavefronts pass over it
+        const u64 instance = item >> a.segs_log2, seg = a.seg_first + (item & ((1ull << a.segs_log2) - 1));
+        bool skip = false;
+        if (MODE == 1) skip = a.amounts[instance] != EC_EMPTY;          // found in an earlier round
+        if (!skip) {
+            const u32 *pi = a.inst + EC_ENTRY_WORDS * instance;
+            const u64 mask = (1ull << a.slot_bits) - 1;
+            const u64 base_step = seg * a.steps_per_item + a.round_first;
+            for (u64 c0 = 0; c0 < a.round_steps; c0 += a.K) {
+                const u32 n = (u32)(a.round_steps - c0 < a.K ? a.round_steps - c0 : a.K);
+                {
+                    const fe cP = ec_load_fe(pi + 20);
+                    fe run = fe_one();
+                    for (u32 k = 0; k < n; k++) {
+                        fe ci; ec_load_c(a.gt + EC_ENTRY_WORDS * (base_step + c0 + k), ci);
+                        run = fe_mul(run, fe_sub(fe_one(), fe_mul(cP, ci)));
+                        ec_scratch_store(a.scratch, a.n_lanes, lane, k, run);
+                    }
+                    fe inv = fe_invert(run);
+                    const fe xP = ec_load_fe(pi), yP = ec_load_fe(pi + 10);
+                    for (u32 k = n; k-- > 0;) {
+                        fe xi, yi, ci; ec_load_entry(a.gt + EC_ENTRY_WORDS * (base_step + c0 + k), xi, yi, ci);
+                        const auto den = fe_sub(fe_one(), fe_mul(cP, ci));
+                        const fe dinv = k ? fe_mul(inv, ec_scratch_load(a.scratch, a.n_lanes, lane, k - 1)) : inv;
+                        inv = fe_mul(inv, den);
+                        const fe y3 = fe_mul(fe_add(fe_mul(yP, yi), fe_mul(xP, xi)), dinv);
+                        u64 slot; u32 fp;
+                        ec_key(y3, slot, fp, a.slot_bits);
+                        u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
+                        sk[0] = (u32)slot; sk[a.n_lanes] = (u32)(slot >> 32); sk[2 * a.n_lanes] = fp;
+                    }
+                }
+                for (u32 k0 = 0; k0 < n; k0 += 8) {
+                    u64 slot[8]; u32 fp[8]; unsigned long long v[8];
+#pragma unroll
+                    for (u32 q = 0; q < 8; q++) {
+                        const u32 k = k0 + q < n ? k0 + q : n - 1;
+                        const u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
+                        slot[q] = (u64)sk[0] | ((u64)sk[a.n_lanes] << 32); fp[q] = sk[2 * a.n_lanes];
+                    }
+                    if (MODE == 1) {
+#pragma unroll
+                        for (u32 q = 0; q < 8; q++) v[q] = a.slots[slot[q] & mask];
+                    }
+#pragma unroll
+                    for (u32 q = 0; q < 8; q++) {
+                        if (k0 + q >= n) continue;
+                        const u64 step = base_step + c0 + k0 + q;
+                        if (MODE == 0) {
+                            const u64 j = item * a.steps_per_item + (step - seg * a.steps_per_item);      // (table build: one segment per instance)
+                            const unsigned long long mine = ((unsigned long long)fp[q] << 32) | (unsigned long long)(u32)j;
+                            for (u32 p = 0; p < EC_MAX_PROBE * 16; p++) {
+                                const unsigned long long old = atomicCAS(&a.slots[(slot[q] + p) & mask], EC_EMPTY, mine);
+                                if (old == EC_EMPTY || old == mine) break;
+                            }
+                        } else {
+                            unsigned long long cur = v[q];
+                            for (u32 p = 0; p < EC_MAX_PROBE && cur != EC_EMPTY; p++) {
+                                if ((u32)(cur >> 32) == fp[q]) {
+                                    const u32 at = atomicAdd(a.cand_count, 1u);
+                                    if (at < a.cand_cap) { u32 *c = a.cand + 4ull * at; c[0] = (u32)instance; c[1] = (u32)step; c[2] = (u32)(step >> 32); c[3] = (u32)cur; }
+                                }
+                                cur = a.slots[(slot[q] + p + 1) & mask];
+                            }
+                        }
+                    }
+                }
+                done += n;
+            }
+        }
+    }
+    if (MODE == 1 && a.steps_done) {
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) done += __shfl_down((unsigned long long)done, d);
+        if ((threadIdx.x & 63) == 0 && done) atomicAdd(a.steps_done, (unsigned long long)done);
+    }
+}
+
+// the same walk at three or four resident wavefronts per SIMD (168 or 128 registers)
+template <int MODE> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ec_bsgs(ec_bsgs_args a) { ec_bsgs_body<MODE>(a); }
+template <int MODE> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ec_bsgs_occ3(ec_bsgs_args a) { ec_bsgs_body<MODE>(a); }
+
+// input -> 4 * point (packed XYZT, for the confirmation) and the affine start 4 * point + offset (x, y, x*y)
+// mode 0: in = 32-byte Ristretto encodings.  mode 1: in = 64-byte ciphertexts (commitment, handle); point = C - s * D.
+__global__ void __launch_bounds__(64) k_ec_prepare(const u8 *__restrict__ in, u32 n, u32 mode, const u32 *__restrict__ secret_words, const u32 *__restrict__ offset_xyzt,
+                                                   u32 *__restrict__ four_p, u32 *__restrict__ inst, u8 *__restrict__ status) {
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    ge p; bool ok;
+    if (mode == 0) ok = ristretto_decode(p, in + 32ull * i);
+    else {
+        ge c, d;
+        ok = ristretto_decode(c, in + 64ull * i);
+        ok = ristretto_decode(d, in + 64ull * i + 32) && ok;
+        if (ok) { u32 s[8]; for (int k = 0; k < 8; k++) s[k] = secret_words[k]; p = ge_sub(c, ec_mul_words(d, s)); }
+    }
+    if (!ok) p = ge_identity();
+    status[i] = ok ? 0 : 1;
+    p = ge_double(ge_double(p));
+    ge_store(four_p + 32ull * i, p);
+    const ge q = ge_add(p, ge_load(offset_xyzt));
+    const fe zinv = fe_invert(q.Z);
+    const fe x = fe_mul(q.X, zinv), y = fe_mul(q.Y, zinv);
+    u32 *e = inst + EC_ENTRY_WORDS * (u64)i;
+    ec_store_fe(e, x); ec_store_fe(e + 10, y); ec_store_fe(e + 20, fe_mul(x, y));
+}
+
+// a candidate (instance, step i, j) stands for m = (2i + 1) 2^b +- j: the one with m * B4 = 4 P is the amount
+__global__ void __launch_bounds__(64) k_ec_confirm(const u32 *__restrict__ cand, const u32 *__restrict__ cand_count, u32 cand_cap, const u32 *__restrict__ four_p,
+                                                   const u32 *__restrict__ b4_xyzt, u32 b, u32 max_bits, unsigned long long *__restrict__ amounts) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    const u32 n = cand_count[0] < cand_cap ? cand_count[0] : cand_cap;
+    if (t >= 2 * n) return;
+    const u32 *c = cand + 4ull * (t >> 1);
+    const u64 step = (u64)c[1] | ((u64)c[2] << 32), j = c[3];
+    const u64 centre = (2 * step + 1) << b;
+    if ((t & 1) && j > centre) return;
+    const u64 m = (t & 1) ? centre - j : centre + j;
+    if (max_bits < 64 && (m >> max_bits)) return;
+    const ge want = ge_load(four_p + 32ull * c[0]);
+    const ge got = ec_mul_u64(ge_load(b4_xyzt), m);
+    // both are points of the prime-order subgroup: plain projective equality
+    if (fe_eq(fe_mul(got.X, want.Z), fe_mul(want.X, got.Z)) && fe_eq(fe_mul(got.Y, want.Z), fe_mul(want.Y, got.Z))) atomicMin(&amounts[c[0]], (unsigned long long)m);
+}
+// 4 * identity = identity has m = 0, which no giant step reaches when max_bits > b + 1 would put 0 at delta = -2^b of step 0:
+// it is covered (j = 2^b is in the table); nothing special is needed.
+
+__global__ void k_ec_fill64(unsigned long long *p, u64 n, unsigned long long v) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_ec_fill32(u32 *p, u32 n, u32 v) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace xhe
+
+struct xhe_ecdlp_table {
+    xhe_ctx *ctx = nullptr;
+    u32 b = 0, slot_bits = 0;
+    ge b4;                                   // 4 G (host copy)
+    dev_buf slots, b4_dev;
+    dev_buf gt; u32 gt_max_bits = 0; u64 gt_steps = 0;         // the giant-step points of the last max_bits asked for
+    xhe_ecdlp_stats last{0, 0, 0.0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+// the Ristretto basepoint G (RISTRETTO_BASEPOINT_COMPRESSED of curve25519-dalek, used at /root/reference/src/elgamal.rs:5)
+ge host_basepoint() {
+    const u8 bb[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                       0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    ge g; ristretto_decode(g, bb);
+    return g;
+}
+// lanes of a grid that is resident at once: waves_per_simd wavefronts on every SIMD
+u64 ec_grid_lanes(xhe_ctx *ctx, u32 waves_per_simd) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    return (u64)cus * 4 * waves_per_simd * 64;
+}
+ge host_mul_u64(const ge &base, u64 m) {
+    ge r = ge_identity();
+    for (int bit = 63; bit >= 0; bit--) { r = ge_double(r); if ((m >> bit) & 1) r = ge_add(r, base); }
+    return r;
+}
+
+// count multiples of `base` from 0, normalised in place: entries (x, y, c) on the device
+int32_t make_affine_multiples(xhe_ctx *ctx, hipStream_t st, const ge &base, u64 count, bool negate, bool times_d, dev_buf &entries) {
+    dev_buf base_dev, scratch;
+    struct release { dev_buf &a, &b; ~release() { a.release(); b.release(); } } guard{base_dev, scratch};
+    HIPCHK(ctx, entries.reserve(count * EC_ENTRY_WORDS * 4));
+    HIPCHK(ctx, base_dev.reserve(128));
+    u32 packed[32]; ge_store(packed, base);
+    HIPCHK(ctx, hipMemcpyAsync(base_dev.p, packed, 128, hipMemcpyHostToDevice, st));
+    const u32 per_lane = count >= (1u << 16) ? 64 : 16;
+    const u64 lanes = (count + per_lane - 1) / per_lane, padded = (lanes + 63) / 64 * 64;
+    HIPCHK(ctx, scratch.reserve(padded * per_lane * 40));
+    hipLaunchKernelGGL(k_ec_multiples, dim3((unsigned)(padded / 64)), dim3(64), 0, st, base_dev.as<u32>(), (u64)0, count, per_lane, entries.as<u32>());
+    hipLaunchKernelGGL(k_ec_normalize, dim3((unsigned)(padded / 64)), dim3(64), 0, st, entries.as<u32>(), count, per_lane, scratch.as<u32>(), padded, negate ? 1u : 0u, times_d ? 1u : 0u);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));          // base_dev and scratch go back to the driver on return
+    return XHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t xhe_ecdlp_table_create(xhe_ctx *ctx, uint32_t table_bits, xhe_ecdlp_table **out) {
+    if (!ctx || !out) return XHE_E_ARG;
+    if (table_bits < 8 || table_bits > 30) { set_error(ctx, "xhe_ecdlp_table_create: table_bits must be 8..30"); return XHE_E_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<xhe_ecdlp_table> t(new xhe_ecdlp_table);
+    t->ctx = ctx; t->b = table_bits; t->slot_bits = table_bits + 1;
+    t->b4 = ge_double(ge_double(host_basepoint()));
+    const u64 n_slots = 1ull << t->slot_bits;
+    struct release_on_error { xhe_ecdlp_table *t; bool armed = true; ~release_on_error() { if (armed) { t->slots.release(); t->b4_dev.release(); } } } guard{t.get()};
+    HIPCHK(ctx, t->slots.reserve(n_slots * 8));
+    HIPCHK(ctx, t->b4_dev.reserve(128));
+    u32 packed[32]; ge_store(packed, t->b4);
+    HIPCHK(ctx, hipMemcpyAsync(t->b4_dev.p, packed, 128, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_ec_fill64, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, t->slots.as<unsigned long long>(), n_slots, EC_EMPTY);
+    // j = chunk * per + k: the chunk starts (chunk * per) B4 play the instances, the points k B4 the table
+    const u32 per = 1u << std::min<u32>(table_bits, 10);
+    const u64 n_chunks = (1ull << table_bits) / per + 1;            // one chunk more: j = 2^b is needed, the rest of it is harmless
+    dev_buf small, starts, scratch;
+    struct release { dev_buf &a, &b, &c; ~release() { a.release(); b.release(); c.release(); } } temporaries{small, starts, scratch};
+    if (int32_t rc = make_affine_multiples(ctx, st, t->b4, per, false, true, small)) return rc;
+    if (int32_t rc = make_affine_multiples(ctx, st, host_mul_u64(t->b4, per), n_chunks, false, false, starts)) return rc;
+    ec_bsgs_args a{};
+    a.inst = starts.as<u32>(); a.n_items = n_chunks; a.n_inst = n_chunks; a.segs_log2 = 0; a.seg_first = 0; a.gt = small.as<u32>(); a.steps_per_item = per; a.round_first = 0; a.round_steps = per;
+    a.K = std::min<u32>(per, 64);
+    a.n_lanes = std::min<u64>((n_chunks + 255) / 256 * 256, ec_grid_lanes(ctx, 4));
+    HIPCHK(ctx, scratch.reserve(a.n_lanes * a.K * 40));
+    a.scratch = scratch.as<u32>(); a.slots = t->slots.as<unsigned long long>(); a.slot_bits = t->slot_bits;
+    hipLaunchKernelGGL(k_ec_bsgs<0>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipEventCreate(&t->ev[0])); HIPCHK(ctx, hipEventCreate(&t->ev[1]));
+    guard.armed = false;
+    *out = t.release();
+    return XHE_OK;
+}
+
+void xhe_ecdlp_table_free(xhe_ecdlp_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    t->slots.release(); t->b4_dev.release(); t->gt.release();
+    for (hipEvent_t e : t->ev) if (e) (void)hipEventDestroy(e);
+    delete t;
+}
+
+static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint32_t mode, const uint8_t *secret32, uint32_t max_bits, int64_t *amounts, uint8_t *status_out) {
+    if (!t || !t->ctx) return XHE_E_ARG;
+    xhe_ctx *ctx = t->ctx;
+    if ((!in && n) || (!amounts && n) || (mode == 1 && !secret32)) return XHE_E_ARG;
+    if (max_bits < 1 || max_bits > 62) { set_error(ctx, "xhe_ecdlp_decode: max_bits must be 1..62"); return XHE_E_ARG; }
+    if (n > (1ull << 24)) { set_error(ctx, "xhe_ecdlp_decode: at most 2^24 points per call"); return XHE_E_ARG; }
+    const u32 b = t->b;
+    const u64 steps = max_bits > b + 1 ? 1ull << (max_bits - b - 1) : 1;
+    if (steps > (1ull << 24)) { set_error(ctx, "xhe_ecdlp_decode: max_bits - table_bits - 1 must not exceed 24 (use a larger table)"); return XHE_E_ARG; }
+    if (!n) return XHE_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (t->gt_max_bits != max_bits) {
+        // the points -i S, S = 2^(b+1) B4
+        ge S = t->b4;
+        for (u32 k = 0; k < b + 1; k++) S = ge_double(S);
+        if (int32_t rc = make_affine_multiples(ctx, st, S, steps, true, true, t->gt)) return rc;
+        t->gt_max_bits = max_bits; t->gt_steps = steps;
+    }
+    dev_buf in_dev, secret_dev, offset_dev, four_p, inst, status, amt, cand, cand_count, scratch, steps_done;
+    struct release { std::vector<dev_buf *> v; ~release() { for (dev_buf *d : v) d->release(); } } temporaries{{&in_dev, &secret_dev, &offset_dev, &four_p, &inst, &status, &amt, &cand, &cand_count, &scratch, &steps_done}};
+    const u64 in_bytes = (mode ? 64ull : 32ull) * n;
+    HIPCHK(ctx, in_dev.reserve(in_bytes)); HIPCHK(ctx, offset_dev.reserve(128)); HIPCHK(ctx, four_p.reserve(128 * n)); HIPCHK(ctx, inst.reserve(EC_ENTRY_WORDS * 4 * n));
+    HIPCHK(ctx, status.reserve(n)); HIPCHK(ctx, amt.reserve(8 * n)); HIPCHK(ctx, cand_count.reserve(64)); HIPCHK(ctx, steps_done.reserve(64)); HIPCHK(ctx, secret_dev.reserve(64));
+    const u32 cand_cap = (u32)std::min<u64>(8 * n + 4096, 1u << 26);
+    HIPCHK(ctx, cand.reserve(16ull * cand_cap));
+    HIPCHK(ctx, hipMemcpyAsync(in_dev.p, in, in_bytes, hipMemcpyHostToDevice, st));
+    u32 secret_words[8] = {0};
+    if (mode == 1) { for (int k = 0; k < 8; k++) secret_words[k] = (u32)secret32[4 * k] | ((u32)secret32[4 * k + 1] << 8) | ((u32)secret32[4 * k + 2] << 16) | ((u32)secret32[4 * k + 3] << 24); }
+    HIPCHK(ctx, hipMemcpyAsync(secret_dev.p, secret_words, 32, hipMemcpyHostToDevice, st));
+    u32 packed[32]; ge_store(packed, ge_neg(host_mul_u64(t->b4, 1ull << b)));
+    HIPCHK(ctx, hipMemcpyAsync(offset_dev.p, packed, 128, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_ec_fill64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amt.as<unsigned long long>(), n, EC_EMPTY);
+    hipLaunchKernelGGL(k_ec_fill64, dim3(1), dim3(64), 0, st, steps_done.as<unsigned long long>(), (u64)1, 0ull);
+    hipLaunchKernelGGL(k_ec_prepare, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in_dev.as<u8>(), (u32)n, mode, secret_dev.as<u32>(), offset_dev.as<u32>(), four_p.as<u32>(), inst.as<u32>(),
+                       status.as<u8>());
+    ec_bsgs_args a{};
+    a.K = (u32)std::min<u64>(EC_CHUNK, steps);
+    const char *occ_env = getenv("XHE_ECDLP_OCC");
+    const bool occ3 = !(occ_env && occ_env[0] == '4');
+    const u64 grid_lanes = ec_grid_lanes(ctx, occ3 ? 3 : 4);
+    // an item is a segment of an instance's range, at least one chunk long; several items per lane even out the lanes whose
+    // instances are found early
+    u32 segs_log2 = 0;
+    while ((n << (segs_log2 + 1)) <= 8 * grid_lanes && (steps >> (segs_log2 + 1)) >= a.K) segs_log2++;
+    // Rounds: after each, the confirmed instances drop out.  A round takes a share of every instance's segments (and, when there
+    // are fewer segments than rounds, a share of every segment's chunks), from the low amounts upwards.
+    // (only while a round still fills the grid: a lone instance is walked in one round)
+    u32 rounds_seg = 1;
+    while (rounds_seg < 8 && 2ull * rounds_seg <= (1ull << segs_log2) && (n << segs_log2) / (2ull * rounds_seg) >= grid_lanes) rounds_seg *= 2;
+    const u32 seg_share_log2 = segs_log2 - (u32)__builtin_ctz(rounds_seg);
+    const u64 steps_per_item = steps >> segs_log2, chunks = steps_per_item / a.K;
+    const u32 rounds_chunk = (n << segs_log2) >= grid_lanes ? (u32)std::min<u64>(8 / rounds_seg, std::max<u64>(1, chunks)) : 1u;
+    a.inst = inst.as<u32>(); a.n_items = n << seg_share_log2; a.n_inst = n; a.segs_log2 = seg_share_log2; a.gt = t->gt.as<u32>(); a.steps_per_item = steps_per_item;
+    a.n_lanes = std::min<u64>((a.n_items + 255) / 256 * 256, grid_lanes);
+    HIPCHK(ctx, scratch.reserve(a.n_lanes * a.K * 40));
+    a.scratch = scratch.as<u32>(); a.slots = t->slots.as<unsigned long long>(); a.slot_bits = t->slot_bits;
+    a.cand = cand.as<u32>(); a.cand_cap = cand_cap; a.cand_count = cand_count.as<u32>(); a.amounts = amt.as<unsigned long long>(); a.steps_done = steps_done.as<unsigned long long>();
+    a.round_steps = steps_per_item / rounds_chunk;
+    HIPCHK(ctx, hipEventRecord(t->ev[0], st));
+    for (u32 r = 0; r < rounds_seg * rounds_chunk; r++) {
+        a.seg_first = (u64)(r / rounds_chunk) << seg_share_log2;
+        a.round_first = (r % rounds_chunk) * a.round_steps;
+        hipLaunchKernelGGL(k_ec_fill32, dim3(1), dim3(64), 0, st, cand_count.as<u32>(), 1u, 0u);
+        if (occ3) hipLaunchKernelGGL(k_ec_bsgs_occ3<1>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_ec_bsgs<1>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_ec_confirm, dim3((2 * cand_cap + 63) / 64), dim3(64), 0, st, cand.as<u32>(), cand_count.as<u32>(), cand_cap, four_p.as<u32>(), t->b4_dev.as<u32>(), b, max_bits,
+                           amt.as<unsigned long long>());
+    }
+    HIPCHK(ctx, hipEventRecord(t->ev[1], st));
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<unsigned long long> host(n);
+    std::vector<u8> host_status(n);
+    unsigned long long done = 0;
+    HIPCHK(ctx, hipMemcpyAsync(host.data(), amt.p, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(host_status.data(), status.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(&done, steps_done.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    float ms = 0; (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[1]);
+    t->last = {n, (uint64_t)done, (double)ms, (uint64_t)a.n_lanes};
+    for (u64 i = 0; i < n; i++) {
+        amounts[i] = (host[i] == EC_EMPTY || host_status[i]) ? -1 : (int64_t)host[i];
+        if (status_out) status_out[i] = host_status[i];
+    }
+    return XHE_OK;
+}
+
+int32_t xhe_ecdlp_decode(xhe_ecdlp_table *t, const uint8_t *points32, uint64_t n, uint32_t max_bits, int64_t *amounts, uint8_t *status) {
+    return ecdlp_run(t, points32, n, 0, nullptr, max_bits, amounts, status);
+}
+int32_t xhe_elgamal_decrypt_decode(xhe_ecdlp_table *t, const uint8_t secret32[32], const uint8_t *cts64, uint64_t n, uint32_t max_bits, int64_t *amounts, uint8_t *status) {
+    return ecdlp_run(t, cts64, n, 1, secret32, max_bits, amounts, status);
+}
+int32_t xhe_ecdlp_last_stats(const xhe_ecdlp_table *t, xhe_ecdlp_stats *out) {
+    if (!t || !out) return XHE_E_ARG;
+    *out = t->last;
+    return XHE_OK;
+}
+
+}  // extern "C"
