@@ -23,3 +23,29 @@ def oracle():
 def hostlib():
     import helpers
     return helpers.load_host_primitives()
+
+
+@pytest.fixture
+def switch():
+    """switch(name, value) sets an XHE_* switch of the library for one test.  The library reads its environment once (when the
+    first context is created), so every change is followed by xhe_settings_reload(); the old values come back afterwards."""
+    import os
+    from xelis_he_amd._capi import load_library
+    lib = load_library()
+    saved = {}
+
+    def set_switch(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        lib.xhe_settings_reload()
+
+    yield set_switch
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    lib.xhe_settings_reload()

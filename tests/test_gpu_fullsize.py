@@ -89,61 +89,61 @@ def test_full_batch_chain_gap(engine, batch):
 
 
 @pytest.mark.timeout(600)
-def test_full_batch_with_term_index_entries(engine, batch, monkeypatch):
+def test_full_batch_with_term_index_entries(engine, batch, switch):
     """The bucket sort normally names point records in its entries; batches of 2^24 points and more keep term indices and the
     accumulation looks the point up.  That form, forced here, gives the same verdicts and the same ledger."""
     v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.setenv("XHE_MSM_TERM_ENTRIES", "1")
+    switch("XHE_MSM_TERM_ENTRIES", "1")
     v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     assert (v0.accept, v1.accept) == (1, 1)
     assert cts0 == cts1
     rec = bytearray(batch.records)
     rec[batch.offsets[4000] + 200] ^= 1               # inside transaction 4000's proofs
     v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.delenv("XHE_MSM_TERM_ENTRIES")
+    switch("XHE_MSM_TERM_ENTRIES", None)
     v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
     assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
 
 
 @pytest.mark.timeout(600)
-def test_full_batch_with_one_pass_sort(engine, batch, monkeypatch):
+def test_full_batch_with_one_pass_sort(engine, batch, switch):
     """The one-pass bucket sort at 14-bit windows (the form inputs beyond 2^24 terms take, all 2^13 counters of a window in
     LDS), forced on the 350 000-term batch: same verdicts, same ledger."""
     v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.setenv("XHE_MSM_ONEPASS", "1")
+    switch("XHE_MSM_ONEPASS", "1")
     v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     assert (v0.accept, v1.accept) == (1, 1)
     assert cts0 == cts1
     rec = bytearray(batch.records)
     rec[batch.offsets[123] + 300] ^= 2
     v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.delenv("XHE_MSM_ONEPASS")
+    switch("XHE_MSM_ONEPASS", None)
     v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
     assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
 
 
 @pytest.mark.timeout(600)
-def test_full_batch_with_register_accumulation(engine, batch, monkeypatch):
+def test_full_batch_with_register_accumulation(engine, batch, switch):
     """The bucket accumulation keeps its prefetched record in LDS; the form with the record in registers (the one entries
     that name terms take), forced here: same verdicts, same ledger."""
     v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.setenv("XHE_MSM_ACC_STAGED", "0")
+    switch("XHE_MSM_ACC_STAGED", "0")
     v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     assert (v0.accept, v1.accept) == (1, 1) and cts0 == cts1
     rec = bytearray(batch.records)
     rec[batch.offsets[2500] + 400] ^= 4
     v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.delenv("XHE_MSM_ACC_STAGED")
+    switch("XHE_MSM_ACC_STAGED", None)
     v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
     assert v2.accept == 0 and (v2.accept, v2.err_code, v2.first_bad_tx) == (v3.accept, v3.err_code, v3.first_bad_tx)
 
 
 @pytest.mark.timeout(600)
-def test_full_batch_cut_into_parts(engine, batch, monkeypatch):
+def test_full_batch_cut_into_parts(engine, batch, switch):
     """Batches from 128 MiB of records on are verified in consecutive parts, each against the ledger the part before it left
     (1 024 senders here, every one with transactions in every part).  Forced on this batch with 4 and 7 parts: the ledger of
     the batch in one piece, a bad signature at its index in the whole batch, a broken chain as GenericProof."""
-    monkeypatch.setenv("XHE_SPLIT_PARTS", "1")
+    switch("XHE_SPLIT_PARTS", "1")
     v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     assert v0.accept == 1
     rec = bytearray(batch.records)
@@ -154,7 +154,7 @@ def test_full_batch_cut_into_parts(engine, batch, monkeypatch):
     gap_records = batch.records[:offs[drop]] + batch.records[offs[drop + 1]:]
     gap_offsets = (ctypes.c_uint64 * batch.n_txs)(*(offs[:drop + 1] + [o - cut for o in offs[drop + 2:]]))
     for parts in ("4", "7"):
-        monkeypatch.setenv("XHE_SPLIT_PARTS", parts)
+        switch("XHE_SPLIT_PARTS", parts)
         v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
         assert v1.accept == 1 and cts1 == cts0, parts
         v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
@@ -164,14 +164,14 @@ def test_full_batch_cut_into_parts(engine, batch, monkeypatch):
 
 
 @pytest.mark.timeout(600)
-def test_full_batch_without_term_merging(engine, batch, monkeypatch):
+def test_full_batch_without_term_merging(engine, batch, switch):
     """Terms that share a point are merged before the bucket sort; unmerged (XHE_MERGE_TERMS=0) the check is the same sum."""
-    monkeypatch.setenv("XHE_MERGE_TERMS", "0")
+    switch("XHE_MERGE_TERMS", "0")
     v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     rec = bytearray(batch.records)
     rec[batch.offsets[9000] + 500] ^= 8
     v2, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.delenv("XHE_MERGE_TERMS")
+    switch("XHE_MERGE_TERMS", None)
     v0, cts0 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     v3, _ = _verify(engine, bytes(rec), batch.offsets, batch.n_txs, batch.view)
     assert (v0.accept, v1.accept) == (1, 1) and cts0 == cts1

@@ -34,14 +34,14 @@ def batch(engine):
 
 
 @pytest.mark.timeout(900)
-def test_headline_accept_and_ledger(engine, batch, monkeypatch):
+def test_headline_accept_and_ledger(engine, batch, switch):
     """Accepted, and the resulting ledger equals the CPU apply path's (Transaction::apply_without_verify per transaction).
     A batch of this size is verified in consecutive parts inside the call: the batch in one piece gives the same bytes."""
     v, cts = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
     assert v.accept == 1, codes.NAMES.get(v.err_code)
-    monkeypatch.setenv("XHE_SPLIT_PARTS", "1")
+    switch("XHE_SPLIT_PARTS", "1")
     v1, cts1 = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
-    monkeypatch.delenv("XHE_SPLIT_PARTS")
+    switch("XHE_SPLIT_PARTS", None)
     assert v1.accept == 1 and cts1 == cts
     lib = _lib()
     view = ctypes.cast(batch.view, ctypes.POINTER(_RawView)).contents

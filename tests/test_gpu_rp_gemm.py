@@ -27,6 +27,7 @@ def _verify_and_read(engine, records, offsets, n_txs, view, min_rows, n_gen):
     lib.xhe_batch_debug_read.restype = ctypes.c_int64
     old = os.environ.get("XHE_RP_GEMM_MIN_ROWS")
     os.environ["XHE_RP_GEMM_MIN_ROWS"] = str(min_rows)
+    lib.xhe_settings_reload()          # the library reads its switches once; this one is used when a batch is uploaded
     ctx, h, v = ctypes.c_void_p(engine.ctx), ctypes.c_void_p(), Verdict()
     try:
         engine._check(lib.xhe_batch_upload(ctx, records, offsets, ctypes.c_uint64(n_txs), view, ctypes.byref(h), ctypes.byref(v)))
@@ -35,6 +36,7 @@ def _verify_and_read(engine, records, offsets, n_txs, view, min_rows, n_gen):
             del os.environ["XHE_RP_GEMM_MIN_ROWS"]
         else:
             os.environ["XHE_RP_GEMM_MIN_ROWS"] = old
+        lib.xhe_settings_reload()
     try:
         engine._check(lib.xhe_batch_verify(ctx, h, ctypes.byref(v), bytes(range(32))))
         out = (ctypes.c_uint8 * (32 * (2 + 2 * n_gen)))()

@@ -9,7 +9,7 @@ import random
 import pytest
 
 from xelis_he_amd import codes
-from xelis_he_amd.api import LedgerOut, SyntheticBatch, Verdict
+from xelis_he_amd.api import LedgerOut, SyntheticBatch, Verdict, _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -29,12 +29,14 @@ class _parts:
     def __enter__(self):
         self.before = os.environ.get("XHE_SPLIT_PARTS")
         os.environ["XHE_SPLIT_PARTS"] = str(self.k)
+        _lib().xhe_settings_reload()            # the library reads its switches once
 
     def __exit__(self, *a):
         if self.before is None:
             del os.environ["XHE_SPLIT_PARTS"]
         else:
             os.environ["XHE_SPLIT_PARTS"] = self.before
+        _lib().xhe_settings_reload()
 
 
 def _verify(engine, oracle, view, records, offsets, n_txs, gpu):

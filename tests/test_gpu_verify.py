@@ -418,12 +418,12 @@ def test_apply_without_verify_batch(engine, oracle):
     assert res[0] == res[1]
 
 
-def test_transcript_stream_in_several_passes(engine, oracle, monkeypatch):
+def test_transcript_stream_in_several_passes(engine, oracle, switch):
     """The transcripts' byte stream is capped per pass (1 GiB); with the cap lowered to two tiles the 300 transactions
     of this batch take three passes over the same buffer and must give the same challenges (verdict and ledger)."""
     sb = SyntheticBatch(300, n_transfers=1, n_senders=20, seed=b"passes-300")
     ref, ref_cts, _ = _raw_verify(None, oracle, None, sb)
-    monkeypatch.setenv("XHE_TRANSCRIPT_CAP_WORDS", str(2 * 21 * 64 * 30))
+    switch("XHE_TRANSCRIPT_CAP_WORDS", str(2 * 21 * 64 * 30))
     got, cts, _ = _raw_verify(engine.lib, engine, engine.ctx, sb)
     assert got == ref == (1, codes.OK, -1) and cts == ref_cts
     bad = bytearray(sb.records)
@@ -433,13 +433,13 @@ def test_transcript_stream_in_several_passes(engine, oracle, monkeypatch):
     assert g == r and g[0] == 0 and g[2] == 280
 
 
-def test_large_batch_schedule_on_a_small_batch(engine, oracle, monkeypatch):
+def test_large_batch_schedule_on_a_small_batch(engine, oracle, switch):
     """Batches of 2048 transactions or more take another schedule (public keys decoded and signatures verified on a stream
     of their own from the start).  XHE_SIG_STREAM_MIN_TXS = 1 runs it on the 256-transaction mixed batch (1.25 signatures
     per transaction, co-signatures included): same verdicts, ledger and failing indices."""
     sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)
     ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb)
-    monkeypatch.setenv("XHE_SIG_STREAM_MIN_TXS", "1")
+    switch("XHE_SIG_STREAM_MIN_TXS", "1")
     got, cts, ms = _raw_verify(engine.lib, engine, engine.ctx, sb)
     assert got == ref == (1, codes.OK, -1)
     assert cts == ref_cts and ms == ref_ms
@@ -455,11 +455,11 @@ def test_large_batch_schedule_on_a_small_batch(engine, oracle, monkeypatch):
     assert _raw_verify(engine.lib, engine, engine.ctx, sb2) == _raw_verify(None, oracle, None, sb2)
 
 
-def test_transcripts_on_one_lane_per_transaction(engine, oracle, monkeypatch):
+def test_transcripts_on_one_lane_per_transaction(engine, oracle, switch):
     """Passes of more than 2048 wavefronts hash the transcripts with one lane per transaction instead of a pair of lanes
     (bit-interleaved state).  XHE_TRANSCRIPT_PAIR_MAX_WAVES = 0 runs that kernel on small batches (five transcript shapes of
     the mixed batch, eight-transfer transactions): same verdicts, ledger and failing index as the oracle."""
-    monkeypatch.setenv("XHE_TRANSCRIPT_PAIR_MAX_WAVES", "0")
+    switch("XHE_TRANSCRIPT_PAIR_MAX_WAVES", "0")
     sb = SyntheticBatch(256, seed=b"mixed-256", mixed=True)
     ref, ref_cts, ref_ms = _raw_verify(None, oracle, None, sb)
     got, cts, ms = _raw_verify(engine.lib, engine, engine.ctx, sb)
@@ -475,13 +475,13 @@ def test_transcripts_on_one_lane_per_transaction(engine, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("n_senders,forced", [(1, None), (3, None), (150, None), (150, "1"), (1, "0")])
-def test_signatures_through_key_tables(engine, oracle, monkeypatch, n_senders, forced):
+def test_signatures_through_key_tables(engine, oracle, switch, n_senders, forced):
     """Batches whose keys sign six or more transactions each add from a table of multiples built once per distinct signing
     key; the others build the table per signature (XHE_SIG_KEY_TABLES forces either).  One key signing the whole batch (the
     reference bench's single chain), a few keys, and as many keys as transactions give the oracle's verdicts on both paths,
     also with a flipped bit in s or e of the first, a middle and the last signature (the error names that transaction)."""
     if forced is not None:
-        monkeypatch.setenv("XHE_SIG_KEY_TABLES", forced)
+        switch("XHE_SIG_KEY_TABLES", forced)
     sb = SyntheticBatch(150, n_transfers=1, n_senders=n_senders, seed=b"key-tables-%d" % n_senders)
     ref, ref_cts, _ = _raw_verify(None, oracle, None, sb)
     got, cts, _ = _raw_verify(engine.lib, engine, engine.ctx, sb)

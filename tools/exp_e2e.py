@@ -20,6 +20,7 @@ settings = sys.argv[4].split(",") if len(sys.argv) > 4 else [None]
 for parts in settings:
     if parts is not None:
         os.environ["XHE_SPLIT_PARTS"] = parts
+        lib.xhe_settings_reload()
     for i in range(reps):
         t0 = time.perf_counter()
         rc = lib.xhe_verify_batch(ctypes.c_void_p(eng.ctx), batch.records, batch.offsets, ctypes.c_uint64(batch.n_txs), batch.view, None, ctypes.byref(v), bytes([i + 1]) * 32)

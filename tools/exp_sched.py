@@ -25,6 +25,7 @@ for e in exps:
         os.environ["XHE_SIG_STREAM_MIN_TXS"] = "4294967295"
     else:
         os.environ.pop("XHE_SIG_STREAM_MIN_TXS", None)
+    lib.xhe_settings_reload()
     acc = {}
     reps = 10
     t0 = None

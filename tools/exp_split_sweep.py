@@ -25,5 +25,6 @@ def run():
 for parts in (4, 6, 8, 10, 12, 16):
     for first, second in ((100, 100), (50, 100), (25, 100), (25, 50), (12, 50), (12, 25)):
         os.environ.update(XHE_SPLIT_PARTS=str(parts), XHE_SPLIT_FIRST=str(first), XHE_SPLIT_SECOND=str(second))
+        lib.xhe_settings_reload()
         med, best = run()
         print("parts %2d first %3d second %3d: median %.2f ms, best %.2f ms" % (parts, first, second, med, best), flush=True)

@@ -2,6 +2,7 @@
 // CPU code: it produces inputs for the verification path (keys, ciphertexts, proofs, signatures,
 // ledgers) and never runs inside it.
 #include <string.h>
+#include "xhe_settings.h"
 #include <map>
 #include <thread>
 #include <atomic>
@@ -227,7 +228,7 @@ xhe_synth *xhe_synth_transfers_gpu(xhe_ctx *ctx, uint64_t n_txs, uint32_t n_tran
     std::atomic<u32> next_sender(0); std::atomic<int> failed(0);
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {           // XHE_SYNTH_TIMES=1: phase times on stderr
-        if (!getenv("XHE_SYNTH_TIMES")) return;
+        if (!setting("XHE_SYNTH_TIMES")) return;
         auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[xhe synth] %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
         t_last = now;
@@ -371,7 +372,7 @@ xhe_synth *xhe_synth_mixed_gpu(xhe_ctx *ctx, uint64_t n_groups, const uint8_t se
     std::atomic<u64> next_group(0); std::atomic<int> failed(0);
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {           // XHE_SYNTH_TIMES=1: phase times on stderr
-        if (!getenv("XHE_SYNTH_TIMES")) return;
+        if (!setting("XHE_SYNTH_TIMES")) return;
         auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[xhe synth mixed] %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
         t_last = now;

@@ -20,6 +20,7 @@
 // Work is spread as (instance, segment of the giant-step range) per lane; lanes of a wavefront either share the table point
 // (many instances) or share the instance (few instances, many segments).
 #include <algorithm>
+#include "xhe_settings.h"
 #include <memory>
 #include <vector>
 #include "xhe_ctx.h"
@@ -430,7 +431,7 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
                        status.as<u8>());
     ec_bsgs_args a{};
     a.K = (u32)std::min<u64>(EC_CHUNK, steps);
-    const char *occ_env = getenv("XHE_ECDLP_OCC");
+    const char *occ_env = setting("XHE_ECDLP_OCC");
     const bool occ3 = !(occ_env && occ_env[0] == '4');
     const u64 grid_lanes = ec_grid_lanes(ctx, occ3 ? 3 : 4);
     // an item is a segment of an instance's range, at least one chunk long; several items per lane even out the lanes whose

@@ -13,6 +13,7 @@
 // before it passed: the verdict takes the failure of the lowest transaction index, for which that assumption holds.
 #pragma once
 #include <stdio.h>
+#include "xhe_settings.h"
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -208,7 +209,7 @@ static inline void ingest_parallel(u64 count, unsigned threads, F fn, ingest_wor
 }
 // host threads of the ingest: XHE_INGEST_THREADS, else the machine's threads, at most 16
 static inline unsigned ingest_thread_count() {
-    if (const char *e = getenv("XHE_INGEST_THREADS")) { unsigned v = (unsigned)strtoul(e, nullptr, 10); if (v >= 1 && v <= 256) return v; }
+    if (const char *e = setting("XHE_INGEST_THREADS")) { unsigned v = (unsigned)strtoul(e, nullptr, 10); if (v >= 1 && v <= 256) return v; }
     unsigned hc = std::thread::hardware_concurrency();
     return hc == 0 ? 1 : (hc > 16 ? 16 : hc);
 }
@@ -273,7 +274,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     if (arena) arena->reset();
     constexpr u32 NONE = 0xffffffffu;
     const unsigned threads = ingest_thread_count();
-    static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
+    const bool show_times = setting("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!show_times) return;

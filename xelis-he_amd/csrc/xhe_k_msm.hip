@@ -23,6 +23,7 @@
 // Points come in as 128-byte affine-Niels records (xhe_ge.h), scalars as canonical 32-byte values.
 // The work per thread of the accumulate stage is M additions whatever the distribution of the digits.
 #include <stdlib.h>
+#include "xhe_settings.h"
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_wide.h"
@@ -67,7 +68,7 @@ msm_plan msm_make_plan(u64 n) {
             if (rounds * m < best_cost) { best_cost = rounds * m; best = m; }
         }
         p.M = best;
-        if (const char *e = getenv("XHE_MSM_CHUNK")) { u32 v = (u32)strtoul(e, nullptr, 10); if (v >= 1 && v <= 1024) p.M = v; }
+        if (const char *e = setting("XHE_MSM_CHUNK")) { u32 v = (u32)strtoul(e, nullptr, 10); if (v >= 1 && v <= 1024) p.M = v; }
     }
     // terms per workgroup of the counting sort: every workgroup reads and writes all B counters of its window, so a tile
     // holds at least two terms per bucket once there are enough tiles (tiles * W workgroups) to cover the chip
@@ -75,7 +76,7 @@ msm_plan msm_make_plan(u64 n) {
     while (p.tile < 2 * p.B && n / (2ull * p.tile) * p.W >= 1024) p.tile *= 2;
     // Large sorts go in two passes (term index in 24 bits + 7 bits of the bucket + sign in one word): scattering straight into
     // 2^13..2^14 buckets per window writes every 4-byte entry to a line of its own, which is what bounds the one-pass form.
-    p.fine_bits = (c >= 14 && n <= (1u << 24) && !getenv("XHE_MSM_ONEPASS")) ? 7 : 0;
+    p.fine_bits = (c >= 14 && n <= (1u << 24) && !setting("XHE_MSM_ONEPASS")) ? 7 : 0;
     return p;
 }
 
@@ -771,7 +772,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     // the two-pass format): the scatter reads the map in term order (coalesced), and the accumulate stage goes from entry to
     // record without a random 4-byte gather per entry in between.
     // (XHE_MSM_TERM_ENTRIES=1 keeps term indices in the entries, the form batches of 2^24 points and more take: for tests)
-    const bool direct = d_term_point && n_points < (p.fine_bits ? (1ull << 24) - 1 : (1ull << 31) - 1) && !getenv("XHE_MSM_TERM_ENTRIES");
+    const bool direct = d_term_point && n_points < (p.fine_bits ? (1ull << 24) - 1 : (1ull << 31) - 1) && !setting("XHE_MSM_TERM_ENTRIES");
     const u32 *entry_point = direct ? d_term_point : nullptr;
     u32 big_cap = (u32)(chunks / MERGE_SPAN_MAX + 15);
     hipError_t e;
@@ -805,7 +806,7 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
     for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
     MARK("msm_accumulate");
     // entries that name point records take the form with the prefetched record in LDS (XHE_MSM_ACC_STAGED=0: the register form)
-    const char *staged_env = getenv("XHE_MSM_ACC_STAGED");
+    const char *staged_env = setting("XHE_MSM_ACC_STAGED");
     if ((direct || !d_term_point) && !(staged_env && staged_env[0] == '0'))
         hipLaunchKernelGGL(k_msm_accumulate, dim3(grid_for(chunks, 256)), dim3(256), 0, st, d_niels, direct ? n_points : n, ws.offsets, ws.sorted, (u32)n_buckets, p.M, ws.buckets, ws.chunk_sums);
     else

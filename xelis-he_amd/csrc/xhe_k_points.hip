@@ -1,6 +1,7 @@
 // Point kernels: batched ristretto decode/encode, constant tables (B, H, Bulletproofs generators, fixed-base
 // tables), decode of a batch's point list, and the error-precedence kernels.
 #include <stdlib.h>
+#include "xhe_settings.h"
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 
@@ -183,8 +184,8 @@ void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases
 void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background) {
     // a bounded grid (grid-stride loop): the decode is the widest kernel of a verification and runs beside the critical path,
     // whose few long-running wavefronts must find free slots the moment they are launched
-    static const u32 max_blocks = getenv("XHE_DECODE_MAX_BLOCKS") ? (u32)strtoul(getenv("XHE_DECODE_MAX_BLOCKS"), nullptr, 10) : DECODE_MAX_BLOCKS;
-    static const bool occ2 = getenv("XHE_DECODE_OCC") && getenv("XHE_DECODE_OCC")[0] == '2';
+    const u32 max_blocks = setting("XHE_DECODE_MAX_BLOCKS") ? (u32)strtoul(setting("XHE_DECODE_MAX_BLOCKS"), nullptr, 10) : DECODE_MAX_BLOCKS;
+    const bool occ2 = setting("XHE_DECODE_OCC") && setting("XHE_DECODE_OCC")[0] == '2';
     u32 blocks = grid_for(n, 256);
     if (blocks > max_blocks) blocks = max_blocks;
     if (!n) return;

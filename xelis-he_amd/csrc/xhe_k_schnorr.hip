@@ -14,6 +14,7 @@
 // A multisig co-signature hashes the 32-byte BLAKE3 digest of the pre-image instead of the message
 // (/root/reference/src/tx/verify.rs:259-292): it has no whole block before R, so only the last kernel hashes.
 #include <stdlib.h>
+#include "xhe_settings.h"
 #include "xhe_dev_common.h"
 #include "xhe_kernels.h"
 #include "xhe_quad.h"
@@ -29,7 +30,7 @@ static constexpr u32 SIG_RATE_WORDS = 9;      // SHA3-512: 72-byte rate
 // 22.6 ms (with fewer the signatures end after everything else).  XHE_SIG_MAX_WAVES overrides the bound.
 static constexpr u32 SIG_MAX_WAVES_DEFAULT = 512;
 static u32 sig_max_waves() {
-    static const u32 v = [] { const char *e = getenv("XHE_SIG_MAX_WAVES"); u32 x = e ? (u32)strtoul(e, nullptr, 10) : 0; return x >= 64 && x <= 65536 ? x : SIG_MAX_WAVES_DEFAULT; }();
+    const u32 v = [] { const char *e = setting("XHE_SIG_MAX_WAVES"); u32 x = e ? (u32)strtoul(e, nullptr, 10) : 0; return x >= 64 && x <= 65536 ? x : SIG_MAX_WAVES_DEFAULT; }();
     return v;
 }
 

@@ -1,5 +1,6 @@
 // Merlin transcript of every transaction and BLAKE3 of multisig pre-images.
 #include "xhe_dev_common.h"
+#include "xhe_settings.h"
 #include "xhe_kernels.h"
 #include "xhe_transcript_template.h"
 
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(64) k_transcript_serial(const u8 *__restrict__
 // wavefront runs one template and its control flow is uniform.
 static constexpr u32 TR_PAD = 0xffffffffu;
 // XHE_TRANSCRIPT_PAIR_MAX_WAVES: largest pass (in wavefronts of the pair kernel) that still runs on lane pairs; 0 = never
-static u64 transcript_pair_max_waves() { const char *e = getenv("XHE_TRANSCRIPT_PAIR_MAX_WAVES"); return e ? strtoull(e, nullptr, 10) : 2048ull; }
+static u64 transcript_pair_max_waves() { const char *e = setting("XHE_TRANSCRIPT_PAIR_MAX_WAVES"); return e ? strtoull(e, nullptr, 10) : 2048ull; }
 static constexpr u32 STAGE_ROWS = 7;         // words of a block handled per pass of a 448-thread workgroup
 
 // the eight bytes of state word l (< 21) of block b through its word descriptor (transcript_word)

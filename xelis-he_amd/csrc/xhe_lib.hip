@@ -2,6 +2,7 @@
 // the HIP stream, the device buffers and the launch sequence, parses records and resolves ledger keys
 // (xhe_ingest.h); all field, group and hash arithmetic of the verification path runs in the kernels.
 #include <hip/hip_runtime.h>
+#include "xhe_settings.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
@@ -43,7 +44,7 @@ static constexpr u32 VERDICT_SLOTS = 4;              // verifications whose verd
 // 10 000-transaction batch: 1.53 ms against 1.59 ms with the signatures behind the bulk decode).  Smaller batches are pure
 // chains of short kernels and keep to three streams.  XHE_SIG_STREAM_MIN_TXS overrides it (the tests run either schedule on
 // small batches).
-static u32 sig_stream_min_txs() { const char *e = getenv("XHE_SIG_STREAM_MIN_TXS"); return e ? (u32)strtoul(e, nullptr, 10) : 2048u; }
+static u32 sig_stream_min_txs() { const char *e = setting("XHE_SIG_STREAM_MIN_TXS"); return e ? (u32)strtoul(e, nullptr, 10) : 2048u; }
 
 struct xhe_batch {
     host_batch hb;             // host tables (kept for reading the ledger back)
@@ -180,6 +181,9 @@ static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verd
 extern "C" {
 
 xhe_ctx *xhe_create(int device_id) {
+    // the XHE_* switches are read here, by the first context of the process (xhe_settings.h)
+    static std::once_flag settings_once;
+    std::call_once(settings_once, [] { settings_load(); });
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) { g_create_error = "no HIP device available"; return nullptr; }
@@ -400,7 +404,7 @@ static void parallel_copy(const std::vector<copy_task> &tasks_in, unsigned threa
 // Range-proof column sums: groups of at least this many transactions go through the matrix cores (xhe_k_rpgemm.hip), smaller
 // ones through the element-by-element kernel, whose cost has no fixed part.  XHE_RP_GEMM_MIN_ROWS overrides the threshold
 // (1: always the matrix path; a huge value: never); it is read when a batch is uploaded and kept with the batch.
-static u64 rp_gemm_min_rows() { const char *e = getenv("XHE_RP_GEMM_MIN_ROWS"); return e ? strtoull(e, nullptr, 10) : 512ull; }
+static u64 rp_gemm_min_rows() { const char *e = setting("XHE_RP_GEMM_MIN_ROWS"); return e ? strtoull(e, nullptr, 10) : 512ull; }
 static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs, const xhe_ledger_view *in, xhe_batch **batch_out,
                                  xhe_verdict *structural, bool wait_for_copies, const ledger_index *shared_index = nullptr) {
     if (!ctx || !offsets || !in || !batch_out || (n_txs && !records)) return XHE_E_ARG;
@@ -411,7 +415,7 @@ static int32_t batch_upload_impl(xhe_ctx *ctx, const uint8_t *records, const uin
     hipStream_t st = ctx->copy_stream;
     auto t_start = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
-        if (!getenv("XHE_UPLOAD_TIMES")) return;
+        if (!setting("XHE_UPLOAD_TIMES")) return;
         auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[xhe upload] %s %.3f ms\n", what, std::chrono::duration<double>(now - t_start).count() * 1e3);
         t_start = now;
@@ -771,7 +775,7 @@ static u32 split_parts_for(u64 n_txs, const u64 *offsets, const xhe_ledger_view 
     if (n_txs < 2) return 1;
     for (u64 i = 0; i < n_txs; i++) if (offsets[i + 1] < offsets[i]) return 1;      // the uncut path names the malformed record
     if (offsets[0] != 0) return 1;
-    if (const char *e = getenv("XHE_SPLIT_PARTS")) {
+    if (const char *e = setting("XHE_SPLIT_PARTS")) {
         const u64 v = strtoull(e, nullptr, 10);
         return v <= 1 ? 1u : (u32)std::min<u64>(std::min<u64>(v, n_txs), 64);
     }
@@ -810,8 +814,8 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
         // XHE_SPLIT_FIRST = its share in per cent of theirs): the device idles while the host parses it.
         const u64 rec_bytes = offsets[n_txs];
         u64 first_pct = 50, second_pct = 100;
-        if (const char *e = getenv("XHE_SPLIT_FIRST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) first_pct = v; }
-        if (const char *e = getenv("XHE_SPLIT_SECOND")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) second_pct = v; }
+        if (const char *e = setting("XHE_SPLIT_FIRST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) first_pct = v; }
+        if (const char *e = setting("XHE_SPLIT_SECOND")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) second_pct = v; }
         std::vector<u64> upto(n_parts + 1, 0);                      // weight of the parts in front of part k
         for (u32 k = 0; k < n_parts; k++) upto[k + 1] = upto[k] + (k == 0 ? first_pct : (k == 1 ? second_pct : 100));
         u64 lo = 0;
@@ -831,14 +835,14 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     // same stream.  A part's verification is enqueued as soon as its upload is in, behind the part in front, which is finished
     // (its verdict read) afterwards: the device goes from one part to the next without waiting for the host.
     // XHE_SPLIT_OVERLAP=0: a part is enqueued only when the part in front has finished (the ledger passes through the host).
-    const char *overlap_env = getenv("XHE_SPLIT_OVERLAP");
+    const char *overlap_env = setting("XHE_SPLIT_OVERLAP");
     const bool overlap = !(overlap_env && overlap_env[0] == '0');
     // consecutive parts alternate between two pairs of streams and two bucket workspaces (XHE_SPLIT_LANES=0: all on one pair)
-    const char *lanes_env = getenv("XHE_SPLIT_LANES");
-    const bool lanes = overlap && !(lanes_env && lanes_env[0] == '0') && !getenv("XHE_ONE_STREAM");
+    const char *lanes_env = setting("XHE_SPLIT_LANES");
+    const bool lanes = overlap && !(lanes_env && lanes_env[0] == '0') && !setting("XHE_ONE_STREAM");
     u32 n_enqueued = 0;
     // (XHE_ONE_STREAM, diagnostics: the verification's ledger work runs on the main stream, so the hand-over does too)
-    hipStream_t s0 = getenv("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];
+    hipStream_t s0 = setting("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];
     dev_buf ledger; ledger.pool = &ctx->pool;
     struct release_ledger { xhe_ctx *c; dev_buf &b; ~release_ledger() { for (hipStream_t s : {c->stream, c->side[0]}) (void)hipStreamSynchronize(s); b.release(); } } ledger_guard{ctx, ledger};
     if (overlap && in->n_balances) {
@@ -909,7 +913,7 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
     u64 key = ~0ull >> 1, malformed_key = ~0ull;      // a malformed record comes before every other error, whichever part holds it
     bool skip_verify = false;
     int32_t rc = 0;
-    static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
+    const bool show_times = setting("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto at = [&](u32 k, const char *what) {
         if (show_times) fprintf(stderr, "[xhe split] part %u %-20s at %.3f ms\n", k, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
@@ -1074,7 +1078,7 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
     if (!ctx || (n_batches && (!batches || !verdicts))) return XHE_E_ARG;
     for (uint64_t k = 0; k < n_batches; k++) if (!batches[k].offsets || !batches[k].in || !batches[k].rng_seed || (batches[k].n_txs && !batches[k].records)) return XHE_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const char *overlap_env = getenv("XHE_BATCHES_OVERLAP");
+    const char *overlap_env = setting("XHE_BATCHES_OVERLAP");
     const bool overlap = !(overlap_env && overlap_env[0] == '0');
     const int timing_level = ctx->timer.level;
     if (overlap) ctx->timer.level = 0;              // stage times are per verification; two are in flight here
@@ -1100,12 +1104,12 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
         }
     });
     auto mark_verified = [&](uint64_t k) { { std::lock_guard<std::mutex> lk(mu); verified = k + 1; } cv.notify_all(); };
-    static const bool show_times = getenv("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
+    const bool show_times = setting("XHE_UPLOAD_TIMES") != nullptr;      // phase times on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto at = [&](uint64_t k, const char *what) {
         if (show_times) fprintf(stderr, "[xhe batches] batch %llu %-12s at %.3f ms\n", (unsigned long long)k, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     };
-    hipStream_t s0 = getenv("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];      // (diagnostics: the ledger work of a verification is on the main stream then)
+    hipStream_t s0 = setting("XHE_ONE_STREAM") ? ctx->stream : ctx->side[0];      // (diagnostics: the ledger work of a verification is on the main stream then)
     int32_t rc = 0;
     // the verdict of an enqueued batch, its ledger, its memory back to the pool
     auto finish_batch = [&](uint64_t k) -> int32_t {
@@ -1225,7 +1229,7 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
                                     int lane_or_none, u32 *carry_ledger) {
     const host_batch &hb = B->hb;
     // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
-    static const bool one_stream = getenv("XHE_ONE_STREAM") != nullptr;
+    const bool one_stream = setting("XHE_ONE_STREAM") != nullptr;
     const bool lanes = lane_or_none >= 0 && !one_stream;
     const u32 lane = lanes ? (u32)lane_or_none & 1u : 0u;
     hipStream_t st = lane ? ctx->side[0] : ctx->stream;
@@ -1238,7 +1242,7 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     stage_timer &tm = ctx->timer;
     tm.begin();
     // XHE_ENQUEUE_TIMES=1: host clock at the points of the launch sequence (how far ahead of the device the enqueueing runs)
-    static const bool host_times = getenv("XHE_ENQUEUE_TIMES") != nullptr;
+    const bool host_times = setting("XHE_ENQUEUE_TIMES") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();
     auto host_mark = [&](const char *what) {
         if (host_times) fprintf(stderr, "[xhe enqueue] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
@@ -1349,7 +1353,7 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     // but the signatures wait for it: it pays when the keys sign many transactions each (measured on one device: 9.8 signatures
     // per key 1.45 -> 1.37 ms; 4 per key with long messages and 2.5 per key slower by 3-4 %).  XHE_SIG_KEY_TABLES = 0 / 1 forces the choice.
     bool key_tables = (u64)n_sigs >= 6ull * hb.sig_keys.size();
-    if (const char *e = getenv("XHE_SIG_KEY_TABLES")) key_tables = e[0] == '1';
+    if (const char *e = setting("XHE_SIG_KEY_TABLES")) key_tables = e[0] == '1';
     if (key_tables) launch_sig_key_tables(ssig, B->sig_keys.as<u32>(), (u32)hb.sig_keys.size(), pts, B->sig_tab.as<u32>());
     launch_sig_point_absorb(ssig, bytes, B->sigs.as<dev_sig>(), n_sigs, key_tables ? B->sig_tab.as<u32>() : nullptr, pts, ctx->htab.as<u32>(), B->sig_r.as<u32>(),
                             B->sig_state.as<u64>());
@@ -1366,7 +1370,7 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
                              sigma_weight_bits(msm_make_plan(tables ? hb.static_term_off : hb.n_terms).c)};
         launch_proof_scalars(st, pa);
         // terms on one point become one term: a value commitment's sigma and range-proof terms, every term on an account's key
-        const char *merge_env = getenv("XHE_MERGE_TERMS");
+        const char *merge_env = setting("XHE_MERGE_TERMS");
         const bool merge_terms = !(merge_env && merge_env[0] == '0');
         if (merge_terms) launch_merge_terms(st, B->merge_pairs.as<u32>(), hb.n_cm + hb.n_xf, B->key_group_off.as<u32>(), (u32)hb.key_group_off.size() - 1, B->key_terms.as<u32>(), scalars);
     }

@@ -8,6 +8,7 @@
 // [7:0] error code.  Every kernel that detects a failure does atomicMin on the transaction's key.
 #pragma once
 #include <stdint.h>
+#include "xhe_settings.h"
 #include <stdlib.h>
 #include <vector>
 #include "xhe_fe.h"
@@ -88,7 +89,7 @@ struct transcript_pass { u32 tile0, n_tiles, max_blocks; };
 struct transcript_plan { std::vector<transcript_pass> passes; u64 stream_words = 0; };
 // stream buffer per pass: 1 GiB, or XHE_TRANSCRIPT_CAP_WORDS 8-byte words (tests lower it to exercise several passes)
 static inline u64 transcript_stream_cap_words() {
-    const char *e = getenv("XHE_TRANSCRIPT_CAP_WORDS");
+    const char *e = setting("XHE_TRANSCRIPT_CAP_WORDS");
     u64 v = e ? strtoull(e, nullptr, 10) : 0;
     return v ? v : (1ull << 27);
 }
