@@ -360,6 +360,44 @@ def measure_config(engine, lib, torch, batch, txs, transfers, mixed, label, step
             "resident": {"ms_per_step": round(r / steps * 1e3, 4), "value": round(txs * steps / r, 1)}, "roofline": roof}
 
 
+def measure_ecdlp(engine, table_bits=24, max_bits=40, n=4096, reps=5):
+    """Balance decoding beside the verification (ECDLPInstance::decode, src/elgamal.rs:68-92): n ciphertexts of random amounts below
+    2^max_bits under one key, decrypted and decoded on the GPU with a baby-step table of 2^table_bits entries.  A giant step is one
+    affine point addition and one 8-byte read at a random place of the table (a 64-byte sector of HBM)."""
+    import random
+    from xelis_he_amd import EcdlpTable
+    from xelis_he_amd.api import Keypair
+    rnd = random.Random(5)
+    kp = Keypair.keygen(b"bench-ecdlp".ljust(32, b"\0"))
+    amounts = [rnd.randrange(1 << max_bits) for _ in range(n)]
+    cts = b"".join(kp.encrypt(a, seed=i.to_bytes(4, "little") + bytes(28)) for i, a in enumerate(amounts))
+    t0 = time.time()
+    table = EcdlpTable(engine, table_bits)
+    build_s = time.time() - t0
+    try:
+        calls, walks, steps = [], [], 0
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            got = table.decrypt_decode(kp.secret, cts, max_bits)
+            calls.append(time.perf_counter() - t0)
+            st = table.last_stats()
+            walks.append(st["walk_ms"]); steps = st["steps"]
+            if got != amounts:
+                raise SystemExit("balance decoding returned a wrong amount")
+        call_s, walk_ms = min(calls[1:]), min(walks[1:])
+    finally:
+        table.close()
+    cal = gather_calibration()
+    out = {"workload": "%d ciphertexts of amounts below 2^%d under one key: decrypt + decode, baby-step table of 2^%d entries (%d MiB)" % (n, max_bits, table_bits, (16 << table_bits) >> 20),
+           "table_build_s": round(build_s, 3), "ms_per_call": round(call_s * 1e3, 3), "value": round(n / call_s, 1), "unit": "balances/s",
+           "giant_steps": steps, "walk_ms": round(walk_ms, 3), "steps_per_s": round(steps / (walk_ms * 1e-3), 1),
+           "table_read_GBps_at_64B_sectors": round(steps * 64 / (walk_ms * 1e-3) / 1e9, 1),
+           "note": "every amount checked against the encrypted one; the giant steps are found-early-exit rounds over 2^(max_bits - table_bits - 1) steps per instance"}
+    if cal and cal.get("kernels", {}).get("gather<4,64>"):
+        out["random_64B_gather_peak_GBps"] = cal["kernels"]["gather<4,64>"]["line_GBps"]
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -578,6 +616,10 @@ def main():
                 configs[key]["generate_s"] = round(g2, 2)
                 b2.close()
 
+    ecdlp = None
+    if rank == 0 and not args.lean and not args.no_secondary and not mixed:
+        ecdlp = measure_ecdlp(engine)
+
     if rank == 0:
         total_txs = args.txs * args.gpus * args.steps
         basis_e2e = args.value_basis == "end_to_end"
@@ -595,7 +637,7 @@ def main():
                        "record_bytes": len(batch.records)},
             "value_basis": args.value_basis,
             ("resident" if basis_e2e else "end_to_end"): beside,
-            "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline, "pipelined": pipelined, "configs": configs,
+            "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu_baseline, "pipelined": pipelined, "configs": configs, "balance_decoding": ecdlp,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stage_detail_ms": {k: round(v, 4) for k, v in detail.items()},
             "setup": {"generate_s": round(gen_s, 2), "range_proofs": "cpu" if gen_engine is None else "gpu", "parse_upload_s": round(resident.upload_s, 4)},
