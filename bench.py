@@ -437,6 +437,15 @@ def main():
                                   "higher_is_better": True, "scaling": "weak", "rccl_error": rccl_error}), flush=True)
             sys.exit(3)
 
+    if world > 1 and "XHE_INGEST_THREADS" not in os.environ:
+        # the ranks share the node's host cores: the uploads' parsing threads are divided among them (the library reads its
+        # switches when its first context is created, below)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 16
+        os.environ["XHE_INGEST_THREADS"] = str(max(4, min(16, cores // world)))
+        args.gen_threads = max(4, min(args.gen_threads, cores // world))
     import xelis_he_amd
     from xelis_he_amd.api import SyntheticBatch, Verdict, _lib
     lib = _lib()
@@ -617,7 +626,7 @@ def main():
                 b2.close()
 
     ecdlp = None
-    if rank == 0 and not args.lean and not args.no_secondary and not mixed:
+    if rank == 0 and dist is None and not args.lean and not args.no_secondary and not mixed:
         ecdlp = measure_ecdlp(engine)
 
     if rank == 0:
