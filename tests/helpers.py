@@ -86,3 +86,41 @@ def oracle_verify_batch(oracle, txs, ledger, seed=b"\x07" * 32, single=False, ap
     if v.accept and apply_on_accept:
         ledger.absorb(f, bytes(out_cts), list(out_nonces), list(ms_set), txs)
     return bool(v.accept), v.err_code, v.first_bad_tx
+
+
+def oracle_verify_in_pieces(oracle, batch, n_pieces=32, threads=16):
+    """A whole synthetic batch through the CPU restatement: cut along its account groups into n_pieces (independent of each
+    other), each piece verified by the oracle against the whole ledger on a host thread of its own.  Returns the pieces'
+    verdicts and the ledger they leave (every slot from the piece that changed it)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from xelis_he_amd import sharding
+    from xelis_he_amd.api import LedgerOut, Verdict
+
+    class RawView(ctypes.Structure):
+        _fields_ = [("n_accounts", ctypes.c_uint64), ("account_keys", ctypes.c_void_p), ("account_nonces", ctypes.c_void_p),
+                    ("n_balances", ctypes.c_uint64), ("balance_account", ctypes.c_void_p), ("balance_assets", ctypes.c_void_p), ("balance_cts", ctypes.c_void_p)]
+    pieces = sharding.cut_for_ranks(batch, n_pieces)
+    assert sum(len(p["index"]) for p in pieces) == batch.n_txs
+    view = ctypes.cast(batch.view, ctypes.POINTER(RawView)).contents
+    n_bal, n_acc = view.n_balances, view.n_accounts
+    start = ctypes.string_at(view.balance_cts, 64 * n_bal)
+    oracle.xo_verify_batch.restype = ctypes.c_int32
+
+    def run(piece):
+        out_cts = (ctypes.c_uint8 * (64 * n_bal))()
+        out = LedgerOut(out_cts, (ctypes.c_uint64 * n_acc)(), (ctypes.c_int64 * n_acc)())
+        pv = Verdict()
+        oracle.xo_verify_batch(piece["records"].ctypes.data_as(ctypes.c_char_p), piece["offsets"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                               ctypes.c_uint64(len(piece["index"])), batch.view, ctypes.byref(out), ctypes.byref(pv), bytes([9]) * 32)
+        return (pv.accept, pv.err_code, pv.first_bad_tx), bytes(out_cts)
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        results = list(pool.map(run, pieces))
+    merged = bytearray(start)
+    for _, out_cts in results:
+        for s in range(n_bal):
+            piece_ct = out_cts[64 * s:64 * s + 64]
+            if piece_ct != start[64 * s:64 * s + 64]:
+                assert merged[64 * s:64 * s + 64] == start[64 * s:64 * s + 64], ("two pieces changed slot", s)
+                merged[64 * s:64 * s + 64] = piece_ct
+    return [r[0] for r in results], bytes(merged)

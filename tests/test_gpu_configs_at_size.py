@@ -198,6 +198,18 @@ def test_mixed_100000_accept_and_ledger(engine, mixed):
 
 
 @pytest.mark.timeout(900)
+def test_mixed_100000_against_the_oracle(engine, oracle, mixed):
+    """All 100 000 mixed transactions through the CPU restatement (32 pieces along the account groups, 16 host threads): every
+    piece accepted, and the ledger the pieces leave equals the GPU verification's byte for byte."""
+    from helpers import oracle_verify_in_pieces
+    v, cts = _verify(engine, mixed.records, mixed.offsets, mixed.n_txs, mixed.view)
+    assert v.accept == 1, codes.NAMES.get(v.err_code)
+    verdicts, merged = oracle_verify_in_pieces(oracle, mixed)
+    assert all(pv == (1, codes.OK, -1) for pv in verdicts)
+    assert merged == cts
+
+
+@pytest.mark.timeout(900)
 def test_mixed_100000_bad_signatures_and_chain_gap(engine, mixed):
     # a co-signature (transaction 14 of group 4 321: the first multisig entry's signature, behind its index byte)
     idx = 16 * 4321 + 14
@@ -246,6 +258,17 @@ def test_share_125000_accept_and_ledger(engine, share):
         assert lib.xhe_tx_apply_host(rec, len(rec), view.n_accounts, keys, view.n_balances, bal_acc, assets, cur) == 0, i
     for s in range(0, 1024, 16):
         assert cts[128 * s:128 * s + 128] == cur.raw[128 * s:128 * s + 128], s
+
+
+@pytest.mark.timeout(900)
+def test_share_125000_against_the_oracle(engine, oracle, share):
+    """All 125 000 transactions through the CPU restatement, as above."""
+    from helpers import oracle_verify_in_pieces
+    v, cts = _verify(engine, share.records, share.offsets, share.n_txs, share.view)
+    assert v.accept == 1, codes.NAMES.get(v.err_code)
+    verdicts, merged = oracle_verify_in_pieces(oracle, share)
+    assert all(pv == (1, codes.OK, -1) for pv in verdicts)
+    assert merged == cts
 
 
 @pytest.mark.timeout(900)

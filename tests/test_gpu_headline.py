@@ -74,6 +74,20 @@ def test_headline_accept_and_ledger(engine, batch, switch):
 
 
 @pytest.mark.timeout(900)
+def test_headline_against_the_oracle_on_every_host_thread(engine, batch, oracle):
+    """The whole 100 000-transaction batch through the CPU restatement: cut along its account groups into 32 pieces (the
+    senders' chains are independent), each piece verified by the oracle against the whole ledger on a host thread of its own
+    (about 1.2 ms per transaction and thread).  Every piece is accepted, and the ledger the pieces leave - every slot from the
+    piece that touched it - equals the GPU verification's ledger byte for byte."""
+    from helpers import oracle_verify_in_pieces
+    v, cts = _verify(engine, batch.records, batch.offsets, batch.n_txs, batch.view)
+    assert v.accept == 1, codes.NAMES.get(v.err_code)
+    verdicts, merged = oracle_verify_in_pieces(oracle, batch)
+    assert all(pv == (1, codes.OK, -1) for pv in verdicts)
+    assert merged == cts
+
+
+@pytest.mark.timeout(900)
 def test_headline_one_bad_signature(engine, batch):
     idx = 77777
     rec = bytearray(batch.records)

@@ -22,9 +22,11 @@ def run():
         ts.append(time.perf_counter() - t0)
         assert rc == 0 and v.accept == 1
     return statistics.median(ts[2:]) * 1e3, min(ts[2:]) * 1e3
-for parts in (4, 6, 8, 10, 12, 16):
-    for first, second in ((100, 100), (50, 100), (25, 100), (25, 50), (12, 50), (12, 25)):
-        os.environ.update(XHE_SPLIT_PARTS=str(parts), XHE_SPLIT_FIRST=str(first), XHE_SPLIT_SECOND=str(second))
-        lib.xhe_settings_reload()
-        med, best = run()
-        print("parts %2d first %3d second %3d: median %.2f ms, best %.2f ms" % (parts, first, second, med, best), flush=True)
+shapes = [(6, 50, 100, 100), (6, 50, 100, 50), (7, 50, 100, 50), (7, 50, 100, 25), (7, 25, 50, 50), (8, 25, 50, 25), (8, 50, 100, 25), (6, 50, 100, 25), (5, 50, 100, 50)]
+if len(sys.argv) > 4 and sys.argv[4] == "full":
+    shapes = [(p, f, s2, 100) for p in (4, 6, 8, 10, 12, 16) for f, s2 in ((100, 100), (50, 100), (25, 100), (25, 50), (12, 50), (12, 25))]
+for parts, first, second, last in shapes:
+    os.environ.update(XHE_SPLIT_PARTS=str(parts), XHE_SPLIT_FIRST=str(first), XHE_SPLIT_SECOND=str(second), XHE_SPLIT_LAST=str(last))
+    lib.xhe_settings_reload()
+    med, best = run()
+    print("parts %2d first %3d second %3d last %3d: median %.2f ms, best %.2f ms" % (parts, first, second, last, med, best), flush=True)

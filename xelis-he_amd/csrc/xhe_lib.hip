@@ -817,7 +817,9 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
         if (const char *e = setting("XHE_SPLIT_FIRST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) first_pct = v; }
         if (const char *e = setting("XHE_SPLIT_SECOND")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) second_pct = v; }
         std::vector<u64> upto(n_parts + 1, 0);                      // weight of the parts in front of part k
-        for (u32 k = 0; k < n_parts; k++) upto[k + 1] = upto[k] + (k == 0 ? first_pct : (k == 1 ? second_pct : 100));
+        u64 last_pct = 100;
+        if (const char *e = setting("XHE_SPLIT_LAST")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 100) last_pct = v; }
+        for (u32 k = 0; k < n_parts; k++) upto[k + 1] = upto[k] + (k == 0 ? first_pct : (k == 1 ? second_pct : (k + 1 == n_parts && n_parts > 2 ? last_pct : 100)));
         u64 lo = 0;
         for (u32 k = 0; k < n_parts; k++) {
             const u64 cut = (u64)((unsigned __int128)rec_bytes * upto[k + 1] / upto[n_parts]);
