@@ -16,9 +16,9 @@
 //       y3 = (y1 y2 + x1 x2) / (1 - d x1 x2 y1 y2)        (complete on this curve: the denominator is never zero)
 //     The denominators of K consecutive steps are inverted together (running products stored in a scratch array, one
 //     inversion per K steps, second pass backwards): 8 field products per step + 265/K for the inversion.
-//   * a hit on the 32 stored bits is a candidate; candidates are confirmed by computing m*B4 (rare, separate small kernel).
-// Work is spread as (instance, segment of the giant-step range) per lane; lanes of a wavefront either share the table point
-// (many instances) or share the instance (few instances, many segments).
+//   * a hit on the 32 stored bits is a candidate, confirmed on the spot by computing m*B4 (rare: a call, not inline code).
+// Work is handed out as items of 128 steps of one instance, the low steps of every instance first; an instance that has been
+// found is passed over from then on (k_ec_bsgs).
 #include <algorithm>
 #include "xhe_settings.h"
 #include <memory>
@@ -124,18 +124,19 @@ __global__ void __launch_bounds__(64) k_ec_normalize(u32 *__restrict__ entries, 
 
 struct ec_bsgs_args {
     const u32 *inst;           // per instance: x, y, x*y (EC_ENTRY_WORDS words)
-    u64 n_items;               // instances << segs_log2: this launch's items
     u64 n_inst;
-    u32 segs_log2;             // an item is (instance, segment seg_first + item mod 2^segs_log2)
-    u64 seg_first;
     const u32 *gt;             // table points: x, y, d*x*y
-    u64 steps_per_item;        // an item's range of table points: [seg * steps_per_item, (seg + 1) * steps_per_item)
-    u64 round_first, round_steps;   // the part of that range this launch walks: [round_first, round_first + round_steps)
-    u32 K;                     // steps per shared inversion
+    u64 steps;                 // table points per instance
+    u32 K;                     // steps per item = steps per shared inversion
+    u64 n_items;               // n_inst * ceil(steps / K); item = chunk * n_inst + instance: the low steps of every instance first
     u32 *scratch; u64 n_lanes; // K * 10 words per lane; n_lanes = the whole grid
     unsigned long long *slots; u32 slot_bits;
+    unsigned long long *next_item;     // the shared item counter of this launch (zero before it)
     // look-up only
-    u32 *cand; u32 cand_cap; u32 *cand_count; const unsigned long long *amounts; unsigned long long *steps_done;
+    unsigned long long *amounts;       // per instance: the amount once it is confirmed, EC_EMPTY until then
+    const u32 *four_p, *b4_xyzt; u32 b, max_bits;
+    unsigned long long *steps_done;
+    u32 *cand; u32 cand_cap; u32 *cand_count;      // MODE 1: candidates (instance, step, j) for k_ec_confirm
 };
 
 __device__ __forceinline__ void ec_key(const fe &y, u64 &slot, u32 &fp, u32 slot_bits) {
@@ -145,98 +146,149 @@ __device__ __forceinline__ void ec_key(const fe &y, u64 &slot, u32 &fp, u32 slot
     fp = w[2] ^ (w[3] * 0x85ebca6bu);
 }
 
-// MODE 0: insert (fp, j) with j = item * steps_per_item + step.  MODE 1: look up, append candidates (instance, step, j).
-// A chunk of K steps goes in three passes: forward (running products of the denominators into the scratch array), backward
-// (the y of every sum; its table slot and check bits replace the running product in the scratch array), then the table:
-// eight independent accesses in flight per lane, which is what hides the latency of a random read in a table of gigabytes.
+// A hit on the table's 32 check bits at giant step `step` with baby step j stands for m = (2 step + 1) 2^b +- j: the one with
+// m * B4 = 4 P is the amount.  Rare (one true hit per instance, a false one per 2^32 look-ups), so it is a call, not inline code.
+__device__ __noinline__ void ec_confirm(const u32 *four_p, const u32 *b4_xyzt, u32 b, u32 max_bits, unsigned long long *amounts, u32 instance, u64 step, u32 j) {
+    const u64 centre = (2 * step + 1) << b;
+    const ge want = ge_load(four_p + 32ull * instance), base = ge_load(b4_xyzt);
+    for (int sign = 0; sign < 2; sign++) {
+        if (sign && j > centre) continue;
+        const u64 m = sign ? centre - j : centre + j;
+        if (max_bits < 64 && (m >> max_bits)) continue;
+        const ge got = ec_mul_u64(base, m);
+        // both are points of the prime-order subgroup: plain projective equality
+        if (fe_eq(fe_mul(got.X, want.Z), fe_mul(want.X, got.Z)) && fe_eq(fe_mul(got.Y, want.Z), fe_mul(want.Y, got.Z))) atomicMin(&amounts[instance], (unsigned long long)m);
+    }
+}
+
+// MODE 0: insert (fp, j) with j = instance * steps + step.  MODE 1: look up, candidates into a list that k_ec_confirm goes
+// through afterwards (when every item is in flight at once anyway: a few instances, whose latency a confirmation inside a
+// wavefront would double).  MODE 2: look up and confirm on the spot, so that found instances drop out while the walk runs.
+// The grid is what the chip holds at once.  A lane keeps its place in the scratch array and takes one item (K steps of one
+// instance) after the other from a shared counter: the lanes of a wavefront that need an item ask for as many as they are in one
+// atomic, and a lane whose new item belongs to an instance that has been found meanwhile asks again - so every lane of every
+// wavefront works on an unfound instance until the items run out, and an instance costs about the steps up to its amount.
+// An item goes in three passes: forward (running products of the denominators into the scratch array), backward (the y of every
+// sum; its table slot and check bits replace the running product in the scratch array), then the table: eight independent
+// accesses in flight per lane, which is what hides the latency of a random read in a table of gigabytes.
 template <int MODE>
 __device__ __forceinline__ void ec_bsgs_body(const ec_bsgs_args &a) {
-    // a lane keeps its place in the scratch array and takes items lane, lane + n_lanes, ...: the grid is what the chip holds at
-    // once, so no wavefront runs in a thin last round
     const u64 lane = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u32 in_wave = threadIdx.x & 63;
+    const u64 mask = (1ull << a.slot_bits) - 1;
     u64 done = 0;
-    for (u64 item = lane; item < a.n_items; item += a.n_lanes) {
-        // neighbouring lanes are segments of one instance: once it is found, whole wavefronts pass over it
-        const u64 instance = item >> a.segs_log2, seg = a.seg_first + (item & ((1ull << a.segs_log2) - 1));
-        bool skip = false;
-        if (MODE == 1) skip = a.amounts[instance] != EC_EMPTY;          // found in an earlier round
-        if (!skip) {
-            const u32 *pi = a.inst + EC_ENTRY_WORDS * instance;
-            const u64 mask = (1ull << a.slot_bits) - 1;
-            const u64 base_step = seg * a.steps_per_item + a.round_first;
-            for (u64 c0 = 0; c0 < a.round_steps; c0 += a.K) {
-                const u32 n = (u32)(a.round_steps - c0 < a.K ? a.round_steps - c0 : a.K);
-                {
-                    const fe cP = ec_load_fe(pi + 20);
-                    fe run = fe_one();
-                    for (u32 k = 0; k < n; k++) {
-                        fe ci; ec_load_c(a.gt + EC_ENTRY_WORDS * (base_step + c0 + k), ci);
-                        run = fe_mul(run, fe_sub(fe_one(), fe_mul(cP, ci)));
-                        ec_scratch_store(a.scratch, a.n_lanes, lane, k, run);
-                    }
-                    fe inv = fe_invert(run);
-                    const fe xP = ec_load_fe(pi), yP = ec_load_fe(pi + 10);
-                    for (u32 k = n; k-- > 0;) {
-                        fe xi, yi, ci; ec_load_entry(a.gt + EC_ENTRY_WORDS * (base_step + c0 + k), xi, yi, ci);
-                        const auto den = fe_sub(fe_one(), fe_mul(cP, ci));
-                        const fe dinv = k ? fe_mul(inv, ec_scratch_load(a.scratch, a.n_lanes, lane, k - 1)) : inv;
-                        inv = fe_mul(inv, den);
-                        const fe y3 = fe_mul(fe_add(fe_mul(yP, yi), fe_mul(xP, xi)), dinv);
-                        u64 slot; u32 fp;
-                        ec_key(y3, slot, fp, a.slot_bits);
-                        u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
-                        sk[0] = (u32)slot; sk[a.n_lanes] = (u32)(slot >> 32); sk[2 * a.n_lanes] = fp;
-                    }
+    bool exhausted = false;
+    for (;;) {
+        // hand out items until every lane has one of an unfound instance, or the items are gone
+        bool have = false;
+        u64 instance = 0, chunk = 0;
+        for (;;) {
+            const unsigned long long need = __ballot(!have && !exhausted);
+            if (!need) break;
+            unsigned long long first = 0;
+            if (in_wave == 0) first = atomicAdd(a.next_item, (unsigned long long)__popcll(need));
+            first = __shfl(first, 0);
+            if (!have && !exhausted) {
+                const u64 item = first + __popcll(need & ((1ull << in_wave) - 1));
+                if (item >= a.n_items) exhausted = true;
+                else {
+                    chunk = item / a.n_inst; instance = item - chunk * a.n_inst;
+                    have = MODE != 2 || __atomic_load_n(&a.amounts[instance], __ATOMIC_RELAXED) == EC_EMPTY;
                 }
-                for (u32 k0 = 0; k0 < n; k0 += 8) {
-                    u64 slot[8]; u32 fp[8]; unsigned long long v[8];
-#pragma unroll
-                    for (u32 q = 0; q < 8; q++) {
-                        const u32 k = k0 + q < n ? k0 + q : n - 1;
-                        const u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
-                        slot[q] = (u64)sk[0] | ((u64)sk[a.n_lanes] << 32); fp[q] = sk[2 * a.n_lanes];
-                    }
-                    if (MODE == 1) {
-#pragma unroll
-                        for (u32 q = 0; q < 8; q++) v[q] = a.slots[slot[q] & mask];
-                    }
-#pragma unroll
-                    for (u32 q = 0; q < 8; q++) {
-                        if (k0 + q >= n) continue;
-                        const u64 step = base_step + c0 + k0 + q;
-                        if (MODE == 0) {
-                            const u64 j = item * a.steps_per_item + (step - seg * a.steps_per_item);      // (table build: one segment per instance)
-                            const unsigned long long mine = ((unsigned long long)fp[q] << 32) | (unsigned long long)(u32)j;
-                            for (u32 p = 0; p < EC_MAX_PROBE * 16; p++) {
-                                const unsigned long long old = atomicCAS(&a.slots[(slot[q] + p) & mask], EC_EMPTY, mine);
-                                if (old == EC_EMPTY || old == mine) break;
-                            }
-                        } else {
-                            unsigned long long cur = v[q];
-                            for (u32 p = 0; p < EC_MAX_PROBE && cur != EC_EMPTY; p++) {
-                                if ((u32)(cur >> 32) == fp[q]) {
-                                    const u32 at = atomicAdd(a.cand_count, 1u);
-                                    if (at < a.cand_cap) { u32 *c = a.cand + 4ull * at; c[0] = (u32)instance; c[1] = (u32)step; c[2] = (u32)(step >> 32); c[3] = (u32)cur; }
-                                }
-                                cur = a.slots[(slot[q] + p + 1) & mask];
-                            }
-                        }
-                    }
-                }
-                done += n;
             }
         }
+        if (!__ballot(have)) break;
+        const u64 base_step = chunk * a.K;
+        const u32 n = have ? (u32)(a.steps - base_step < a.K ? a.steps - base_step : a.K) : 0u;
+        const u32 *pi = a.inst + EC_ENTRY_WORDS * instance;
+        {
+            const fe cP = ec_load_fe(pi + 20);
+            fe run = fe_one();
+            for (u32 k = 0; k < n; k++) {
+                fe ci; ec_load_c(a.gt + EC_ENTRY_WORDS * (base_step + k), ci);
+                run = fe_mul(run, fe_sub(fe_one(), fe_mul(cP, ci)));
+                ec_scratch_store(a.scratch, a.n_lanes, lane, k, run);
+            }
+            fe inv = fe_invert(run);
+            const fe xP = ec_load_fe(pi), yP = ec_load_fe(pi + 10);
+            for (u32 k = n; k-- > 0;) {
+                fe xi, yi, ci; ec_load_entry(a.gt + EC_ENTRY_WORDS * (base_step + k), xi, yi, ci);
+                const auto den = fe_sub(fe_one(), fe_mul(cP, ci));
+                const fe dinv = k ? fe_mul(inv, ec_scratch_load(a.scratch, a.n_lanes, lane, k - 1)) : inv;
+                inv = fe_mul(inv, den);
+                const fe y3 = fe_mul(fe_add(fe_mul(yP, yi), fe_mul(xP, xi)), dinv);
+                u64 slot; u32 fp;
+                ec_key(y3, slot, fp, a.slot_bits);
+                u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
+                sk[0] = (u32)slot; sk[a.n_lanes] = (u32)(slot >> 32); sk[2 * a.n_lanes] = fp;
+            }
+        }
+        for (u32 k0 = 0; k0 < n; k0 += 8) {
+            u64 slot[8]; u32 fp[8]; unsigned long long v[8];
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) {
+                const u32 k = k0 + q < n ? k0 + q : n - 1;
+                const u32 *sk = a.scratch + ((u64)k * 10) * a.n_lanes + lane;
+                slot[q] = (u64)sk[0] | ((u64)sk[a.n_lanes] << 32); fp[q] = sk[2 * a.n_lanes];
+            }
+            if (MODE != 0) {
+#pragma unroll
+                for (u32 q = 0; q < 8; q++) v[q] = a.slots[slot[q] & mask];
+            }
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) {
+                if (k0 + q >= n) continue;
+                const u64 step = base_step + k0 + q;
+                if (MODE == 0) {
+                    const unsigned long long mine = ((unsigned long long)fp[q] << 32) | (unsigned long long)(u32)(instance * a.steps + step);
+                    for (u32 p = 0; p < EC_MAX_PROBE * 16; p++) {
+                        const unsigned long long old = atomicCAS(&a.slots[(slot[q] + p) & mask], EC_EMPTY, mine);
+                        if (old == EC_EMPTY || old == mine) break;
+                    }
+                } else {
+                    unsigned long long cur = v[q];
+                    for (u32 p = 0; p < EC_MAX_PROBE && cur != EC_EMPTY; p++) {
+                        if ((u32)(cur >> 32) == fp[q]) {
+                            if (MODE == 2) ec_confirm(a.four_p, a.b4_xyzt, a.b, a.max_bits, a.amounts, (u32)instance, step, (u32)cur);
+                            else {
+                                const u32 at = atomicAdd(a.cand_count, 1u);
+                                if (at < a.cand_cap) { u32 *c = a.cand + 4ull * at; c[0] = (u32)instance; c[1] = (u32)step; c[2] = (u32)(step >> 32); c[3] = (u32)cur; }
+                            }
+                        }
+                        cur = a.slots[(slot[q] + p + 1) & mask];
+                    }
+                }
+            }
+        }
+        done += n;
     }
-    if (MODE == 1 && a.steps_done) {
+    if (MODE != 0 && a.steps_done) {
 #pragma unroll
         for (u32 d = 32; d >= 1; d >>= 1) done += __shfl_down((unsigned long long)done, d);
-        if ((threadIdx.x & 63) == 0 && done) atomicAdd(a.steps_done, (unsigned long long)done);
+        if (in_wave == 0 && done) atomicAdd(a.steps_done, (unsigned long long)done);
     }
 }
 
 // the same walk at three or four resident wavefronts per SIMD (168 or 128 registers)
 template <int MODE> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ec_bsgs(ec_bsgs_args a) { ec_bsgs_body<MODE>(a); }
 template <int MODE> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ec_bsgs_occ3(ec_bsgs_args a) { ec_bsgs_body<MODE>(a); }
+
+// the candidates of a MODE 1 walk, both signs of each on a thread of its own
+__global__ void __launch_bounds__(64) k_ec_confirm(const u32 *__restrict__ cand, const u32 *__restrict__ cand_count, u32 cand_cap, const u32 *__restrict__ four_p,
+                                                   const u32 *__restrict__ b4_xyzt, u32 b, u32 max_bits, unsigned long long *__restrict__ amounts) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    const u32 n = cand_count[0] < cand_cap ? cand_count[0] : cand_cap;
+    if (t >= 2 * n) return;
+    const u32 *c = cand + 4ull * (t >> 1);
+    const u64 step = (u64)c[1] | ((u64)c[2] << 32), j = c[3];
+    const u64 centre = (2 * step + 1) << b;
+    if ((t & 1) && j > centre) return;
+    const u64 m = (t & 1) ? centre - j : centre + j;
+    if (max_bits < 64 && (m >> max_bits)) return;
+    const ge want = ge_load(four_p + 32ull * c[0]);
+    const ge got = ec_mul_u64(ge_load(b4_xyzt), m);
+    if (fe_eq(fe_mul(got.X, want.Z), fe_mul(want.X, got.Z)) && fe_eq(fe_mul(got.Y, want.Z), fe_mul(want.Y, got.Z))) atomicMin(&amounts[c[0]], (unsigned long long)m);
+}
 
 // input -> 4 * point (packed XYZT, for the confirmation) and the affine start 4 * point + offset (x, y, x*y)
 // mode 0: in = 32-byte Ristretto encodings.  mode 1: in = 64-byte ciphertexts (commitment, handle); point = C - s * D.
@@ -262,26 +314,6 @@ __global__ void __launch_bounds__(64) k_ec_prepare(const u8 *__restrict__ in, u3
     u32 *e = inst + EC_ENTRY_WORDS * (u64)i;
     ec_store_fe(e, x); ec_store_fe(e + 10, y); ec_store_fe(e + 20, fe_mul(x, y));
 }
-
-// a candidate (instance, step i, j) stands for m = (2i + 1) 2^b +- j: the one with m * B4 = 4 P is the amount
-__global__ void __launch_bounds__(64) k_ec_confirm(const u32 *__restrict__ cand, const u32 *__restrict__ cand_count, u32 cand_cap, const u32 *__restrict__ four_p,
-                                                   const u32 *__restrict__ b4_xyzt, u32 b, u32 max_bits, unsigned long long *__restrict__ amounts) {
-    const u32 t = blockIdx.x * 64 + threadIdx.x;
-    const u32 n = cand_count[0] < cand_cap ? cand_count[0] : cand_cap;
-    if (t >= 2 * n) return;
-    const u32 *c = cand + 4ull * (t >> 1);
-    const u64 step = (u64)c[1] | ((u64)c[2] << 32), j = c[3];
-    const u64 centre = (2 * step + 1) << b;
-    if ((t & 1) && j > centre) return;
-    const u64 m = (t & 1) ? centre - j : centre + j;
-    if (max_bits < 64 && (m >> max_bits)) return;
-    const ge want = ge_load(four_p + 32ull * c[0]);
-    const ge got = ec_mul_u64(ge_load(b4_xyzt), m);
-    // both are points of the prime-order subgroup: plain projective equality
-    if (fe_eq(fe_mul(got.X, want.Z), fe_mul(want.X, got.Z)) && fe_eq(fe_mul(got.Y, want.Z), fe_mul(want.Y, got.Z))) atomicMin(&amounts[c[0]], (unsigned long long)m);
-}
-// 4 * identity = identity has m = 0, which no giant step reaches when max_bits > b + 1 would put 0 at delta = -2^b of step 0:
-// it is covered (j = 2^b is in the table); nothing special is needed.
 
 __global__ void k_ec_fill64(unsigned long long *p, u64 n, unsigned long long v) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,11 +402,17 @@ int32_t xhe_ecdlp_table_create(xhe_ctx *ctx, uint32_t table_bits, xhe_ecdlp_tabl
     if (int32_t rc = make_affine_multiples(ctx, st, t->b4, per, false, true, small)) return rc;
     if (int32_t rc = make_affine_multiples(ctx, st, host_mul_u64(t->b4, per), n_chunks, false, false, starts)) return rc;
     ec_bsgs_args a{};
-    a.inst = starts.as<u32>(); a.n_items = n_chunks; a.n_inst = n_chunks; a.segs_log2 = 0; a.seg_first = 0; a.gt = small.as<u32>(); a.steps_per_item = per; a.round_first = 0; a.round_steps = per;
+    a.inst = starts.as<u32>(); a.n_inst = n_chunks; a.gt = small.as<u32>(); a.steps = per;
     a.K = std::min<u32>(per, 64);
-    a.n_lanes = std::min<u64>((n_chunks + 255) / 256 * 256, ec_grid_lanes(ctx, 4));
+    a.n_items = n_chunks * ((per + a.K - 1) / a.K);
+    a.n_lanes = std::min<u64>((a.n_items + 255) / 256 * 256, ec_grid_lanes(ctx, 4));
     HIPCHK(ctx, scratch.reserve(a.n_lanes * a.K * 40));
     a.scratch = scratch.as<u32>(); a.slots = t->slots.as<unsigned long long>(); a.slot_bits = t->slot_bits;
+    dev_buf counter;
+    struct release_counter { dev_buf &c; ~release_counter() { c.release(); } } counter_guard{counter};
+    HIPCHK(ctx, counter.reserve(64));
+    hipLaunchKernelGGL(k_ec_fill64, dim3(1), dim3(64), 0, st, counter.as<unsigned long long>(), (u64)1, 0ull);
+    a.next_item = counter.as<unsigned long long>();
     hipLaunchKernelGGL(k_ec_bsgs<0>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st));
@@ -412,13 +450,11 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
         if (int32_t rc = make_affine_multiples(ctx, st, S, steps, true, true, t->gt)) return rc;
         t->gt_max_bits = max_bits; t->gt_steps = steps;
     }
-    dev_buf in_dev, secret_dev, offset_dev, four_p, inst, status, amt, cand, cand_count, scratch, steps_done;
-    struct release { std::vector<dev_buf *> v; ~release() { for (dev_buf *d : v) d->release(); } } temporaries{{&in_dev, &secret_dev, &offset_dev, &four_p, &inst, &status, &amt, &cand, &cand_count, &scratch, &steps_done}};
+    dev_buf in_dev, secret_dev, offset_dev, four_p, inst, status, amt, scratch, steps_done, cand;
+    struct release { std::vector<dev_buf *> v; ~release() { for (dev_buf *d : v) d->release(); } } temporaries{{&in_dev, &secret_dev, &offset_dev, &four_p, &inst, &status, &amt, &scratch, &steps_done, &cand}};
     const u64 in_bytes = (mode ? 64ull : 32ull) * n;
     HIPCHK(ctx, in_dev.reserve(in_bytes)); HIPCHK(ctx, offset_dev.reserve(128)); HIPCHK(ctx, four_p.reserve(128 * n)); HIPCHK(ctx, inst.reserve(EC_ENTRY_WORDS * 4 * n));
-    HIPCHK(ctx, status.reserve(n)); HIPCHK(ctx, amt.reserve(8 * n)); HIPCHK(ctx, cand_count.reserve(64)); HIPCHK(ctx, steps_done.reserve(64)); HIPCHK(ctx, secret_dev.reserve(64));
-    const u32 cand_cap = (u32)std::min<u64>(8 * n + 4096, 1u << 26);
-    HIPCHK(ctx, cand.reserve(16ull * cand_cap));
+    HIPCHK(ctx, status.reserve(n)); HIPCHK(ctx, amt.reserve(8 * n)); HIPCHK(ctx, steps_done.reserve(64)); HIPCHK(ctx, secret_dev.reserve(64));
     HIPCHK(ctx, hipMemcpyAsync(in_dev.p, in, in_bytes, hipMemcpyHostToDevice, st));
     u32 secret_words[8] = {0};
     if (mode == 1) { for (int k = 0; k < 8; k++) secret_words[k] = (u32)secret32[4 * k] | ((u32)secret32[4 * k + 1] << 8) | ((u32)secret32[4 * k + 2] << 16) | ((u32)secret32[4 * k + 3] << 24); }
@@ -426,7 +462,7 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
     u32 packed[32]; ge_store(packed, ge_neg(host_mul_u64(t->b4, 1ull << b)));
     HIPCHK(ctx, hipMemcpyAsync(offset_dev.p, packed, 128, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_ec_fill64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amt.as<unsigned long long>(), n, EC_EMPTY);
-    hipLaunchKernelGGL(k_ec_fill64, dim3(1), dim3(64), 0, st, steps_done.as<unsigned long long>(), (u64)1, 0ull);
+    hipLaunchKernelGGL(k_ec_fill64, dim3(1), dim3(64), 0, st, steps_done.as<unsigned long long>(), (u64)3, 0ull);     // steps walked, item counter, candidate counter
     hipLaunchKernelGGL(k_ec_prepare, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in_dev.as<u8>(), (u32)n, mode, secret_dev.as<u32>(), offset_dev.as<u32>(), four_p.as<u32>(), inst.as<u32>(),
                        status.as<u8>());
     ec_bsgs_args a{};
@@ -434,33 +470,28 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
     const char *occ_env = setting("XHE_ECDLP_OCC");
     const bool occ3 = !(occ_env && occ_env[0] == '4');
     const u64 grid_lanes = ec_grid_lanes(ctx, occ3 ? 3 : 4);
-    // an item is a segment of an instance's range, at least one chunk long; several items per lane even out the lanes whose
-    // instances are found early
-    u32 segs_log2 = 0;
-    while ((n << (segs_log2 + 1)) <= 8 * grid_lanes && (steps >> (segs_log2 + 1)) >= a.K) segs_log2++;
-    // Rounds: after each, the confirmed instances drop out.  A round takes a share of every instance's segments (and, when there
-    // are fewer segments than rounds, a share of every segment's chunks), from the low amounts upwards.
-    // (only while a round still fills the grid: a lone instance is walked in one round)
-    u32 rounds_seg = 1;
-    while (rounds_seg < 8 && 2ull * rounds_seg <= (1ull << segs_log2) && (n << segs_log2) / (2ull * rounds_seg) >= grid_lanes) rounds_seg *= 2;
-    const u32 seg_share_log2 = segs_log2 - (u32)__builtin_ctz(rounds_seg);
-    const u64 steps_per_item = steps >> segs_log2, chunks = steps_per_item / a.K;
-    const u32 rounds_chunk = (n << segs_log2) >= grid_lanes ? (u32)std::min<u64>(8 / rounds_seg, std::max<u64>(1, chunks)) : 1u;
-    a.inst = inst.as<u32>(); a.n_items = n << seg_share_log2; a.n_inst = n; a.segs_log2 = seg_share_log2; a.gt = t->gt.as<u32>(); a.steps_per_item = steps_per_item;
+    a.inst = inst.as<u32>(); a.n_inst = n; a.gt = t->gt.as<u32>(); a.steps = steps; a.n_items = n * ((steps + a.K - 1) / a.K);
     a.n_lanes = std::min<u64>((a.n_items + 255) / 256 * 256, grid_lanes);
     HIPCHK(ctx, scratch.reserve(a.n_lanes * a.K * 40));
     a.scratch = scratch.as<u32>(); a.slots = t->slots.as<unsigned long long>(); a.slot_bits = t->slot_bits;
-    a.cand = cand.as<u32>(); a.cand_cap = cand_cap; a.cand_count = cand_count.as<u32>(); a.amounts = amt.as<unsigned long long>(); a.steps_done = steps_done.as<unsigned long long>();
-    a.round_steps = steps_per_item / rounds_chunk;
+    a.amounts = amt.as<unsigned long long>(); a.four_p = four_p.as<u32>(); a.b4_xyzt = t->b4_dev.as<u32>(); a.b = b; a.max_bits = max_bits;
+    a.steps_done = steps_done.as<unsigned long long>(); a.next_item = steps_done.as<unsigned long long>() + 1;
+    // every item in flight at once: nothing can drop out early, candidates go through a list and a kernel of their own
+    const bool listed = a.n_items <= a.n_lanes;
+    const u32 cand_cap = (u32)(8 * n + 4096);
+    if (listed) {
+        HIPCHK(ctx, cand.reserve(16ull * cand_cap));
+        a.cand = cand.as<u32>(); a.cand_cap = cand_cap; a.cand_count = (u32 *)(steps_done.as<unsigned long long>() + 2);
+    }
     HIPCHK(ctx, hipEventRecord(t->ev[0], st));
-    for (u32 r = 0; r < rounds_seg * rounds_chunk; r++) {
-        a.seg_first = (u64)(r / rounds_chunk) << seg_share_log2;
-        a.round_first = (r % rounds_chunk) * a.round_steps;
-        hipLaunchKernelGGL(k_ec_fill32, dim3(1), dim3(64), 0, st, cand_count.as<u32>(), 1u, 0u);
+    if (listed) {
         if (occ3) hipLaunchKernelGGL(k_ec_bsgs_occ3<1>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_ec_bsgs<1>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_ec_confirm, dim3((2 * cand_cap + 63) / 64), dim3(64), 0, st, cand.as<u32>(), cand_count.as<u32>(), cand_cap, four_p.as<u32>(), t->b4_dev.as<u32>(), b, max_bits,
+        hipLaunchKernelGGL(k_ec_confirm, dim3((2 * cand_cap + 63) / 64), dim3(64), 0, st, cand.as<u32>(), a.cand_count, cand_cap, four_p.as<u32>(), t->b4_dev.as<u32>(), b, max_bits,
                            amt.as<unsigned long long>());
+    } else {
+        if (occ3) hipLaunchKernelGGL(k_ec_bsgs_occ3<2>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_ec_bsgs<2>, dim3((unsigned)(a.n_lanes / 256)), dim3(256), 0, st, a);
     }
     HIPCHK(ctx, hipEventRecord(t->ev[1], st));
     HIPCHK(ctx, hipGetLastError());
