@@ -99,3 +99,18 @@ def test_many_instances_and_wide_range(engine):
         assert t.decrypt_decode(kp.secret, cts[:64 * 3], 39) == [0, None, None]
     finally:
         t.close()
+
+
+@pytest.mark.timeout(600)
+def test_48_bit_balances_with_a_gigabyte_table(engine):
+    """A table of 2^26 baby steps (1 GiB) and amounts below 2^48, the width a wallet balance in atomic units needs."""
+    rnd = random.Random(13)
+    t = EcdlpTable(engine, 26)
+    try:
+        kp = Keypair.keygen(b"ecdlp-48".ljust(32, b"\0"))
+        amounts = [0, (1 << 48) - 1, 1 << 47, (1 << 27) - 1, 1 << 27, (1 << 27) + 1] + [rnd.randrange(1 << 48) for _ in range(58)]
+        cts = b"".join(kp.encrypt(a, seed=i.to_bytes(4, "little") + bytes(28)) for i, a in enumerate(amounts))
+        assert t.decrypt_decode(kp.secret, cts, 48) == amounts
+        assert t.decrypt_decode(kp.secret, cts[:64 * 3], 47) == [0, None, None]
+    finally:
+        t.close()

@@ -32,7 +32,7 @@ namespace xhe {
 
 static constexpr u32 EC_ENTRY_WORDS = 32;                  // x[10], y[10], c[10] raw limbs, 2 unused: 128 bytes
 static constexpr unsigned long long EC_EMPTY = ~0ull;
-static constexpr u32 EC_MAX_PROBE = 64;
+static constexpr u32 EC_MAX_PROBE = 1024;                  // slots a look-up or an insertion walks at most (the table is half empty: runs of tens of slots are already rare)
 static constexpr u32 EC_CHUNK = 128;                       // steps per shared inversion (and per lane's share of the scratch array)
 
 __device__ __forceinline__ fe ec_load_fe(const u32 *p) { fe r; for (int i = 0; i < 10; i++) r.v[i] = p[i]; return r; }
@@ -241,7 +241,7 @@ __device__ __forceinline__ void ec_bsgs_body(const ec_bsgs_args &a) {
                 const u64 step = base_step + k0 + q;
                 if (MODE == 0) {
                     const unsigned long long mine = ((unsigned long long)fp[q] << 32) | (unsigned long long)(u32)(instance * a.steps + step);
-                    for (u32 p = 0; p < EC_MAX_PROBE * 16; p++) {
+                    for (u32 p = 0; p < EC_MAX_PROBE; p++) {
                         const unsigned long long old = atomicCAS(&a.slots[(slot[q] + p) & mask], EC_EMPTY, mine);
                         if (old == EC_EMPTY || old == mine) break;
                     }
