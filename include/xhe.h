@@ -241,7 +241,7 @@ typedef struct xhe_msm_stats { uint64_t launches; uint64_t entries; uint64_t ter
 int32_t xhe_msm_stats_enable(xhe_ctx *ctx, int32_t on);
 int32_t xhe_msm_stats_read(xhe_ctx *ctx, xhe_msm_stats *out, int32_t reset);
 
-/* The library's XHE_* environment switches (diagnostics, A/B measurements, tests: INTEGRATION.md lists them; none is needed in
+/* The library's XHE_* environment switches (diagnostics, A/B measurements, tests; none is needed in
  * production) are read once, when the first context of the process is created.  This call reads them again: for tests and
  * measurement tools that change a switch inside one process.  Not to be called while another thread is inside the library.
  * No counterpart in the reference. */
