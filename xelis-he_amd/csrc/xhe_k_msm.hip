@@ -422,6 +422,136 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort(const u32 *__restrict__ t
     }
 }
 
+// ---- the two passes with their writes staged in LDS ---------------------------------------------------
+// The kernels above write every entry where its counter says, four bytes at a time to as many places as there are bins: the
+// memory system combines only part of that (WRITE_SIZE: 3.2 and 2.3 times the bytes stored).  Here a workgroup takes its
+// entries a few thousand at a time, orders them by bin inside LDS (count, scan, place) and then writes the LDS buffer out in
+// order: consecutive entries of the buffer belong to one bin and go to consecutive addresses, whole lines at a time.
+static constexpr u32 STAGE_PER_THREAD = 8;
+// exclusive scan of cnt[0..nb) (nb <= 256) by the workgroup's first nb threads; returns this thread's own count and start
+__device__ __forceinline__ void staged_scan(u32 *cnt, u32 *scan, u32 nb, u32 t, u32 &own, u32 &start) {
+    own = t < nb ? cnt[t] : 0;
+    if (t < nb) scan[t] = own;
+    __syncthreads();
+    for (u32 d = 1; d < nb; d <<= 1) {
+        u32 o = (t < nb && t >= d) ? scan[t - d] : 0;
+        __syncthreads();
+        if (t < nb) scan[t] += o;
+        __syncthreads();
+    }
+    start = t < nb ? scan[t] - own : 0;
+}
+__global__ void __launch_bounds__(512) k_msm_coarse_scatter_staged(const unsigned short *__restrict__ digits, u64 n, msm_plan p, u32 tiles, const u32 *__restrict__ tile_hist,
+                                                                   const u32 *__restrict__ coarse_off, u32 *__restrict__ tmp, u64 cap, const u32 *__restrict__ entry_point, u32 n_points) {
+    wave_priority_high();
+    constexpr u32 SUB = 512 * STAGE_PER_THREAD;
+    __shared__ u32 stage_val[SUB];
+    __shared__ unsigned char stage_bin[SUB];
+    __shared__ u32 gcur[256], lcnt[256], scan[256], delta[256];
+    __shared__ u32 total_sh;
+    const u32 tile = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits, fine_mask = (1u << p.fine_bits) - 1, t = threadIdx.x;
+    const u32 *pre = tile_hist + ((u64)w * tiles + tile) * nb;
+    const u32 *off = coarse_off + (u64)w * nb;
+    if (t < nb) { gcur[t] = off[t] + pre[t]; lcnt[t] = 0; }
+    __syncthreads();
+    const u64 lo = (u64)tile * p.tile, hi = lo + p.tile < n ? lo + p.tile : n;
+    const unsigned short *dg = digits + (u64)w * n;
+    for (u64 base = lo; base < hi; base += SUB) {
+        u32 dv[STAGE_PER_THREAD];
+#pragma unroll
+        for (u32 j = 0; j < STAGE_PER_THREAD; j++) { const u64 k = base + t + (u64)j * 512; dv[j] = k < hi ? (u32)dg[k] : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < STAGE_PER_THREAD; j++) { const u32 a = dv[j] & 0x7fffu; if (a) atomicAdd(&lcnt[(a - 1) >> p.fine_bits], 1u); }
+        __syncthreads();
+        u32 own, start;
+        staged_scan(lcnt, scan, nb, t, own, start);
+        if (t < nb) { delta[t] = gcur[t] - start; lcnt[t] = start; }          // lcnt becomes the bin's cursor inside the stage
+        if (t == nb - 1) total_sh = start + own;
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < STAGE_PER_THREAD; j++) {
+            const u32 d = dv[j], a = d & 0x7fffu;
+            if (a) {
+                const u32 bin = (a - 1) >> p.fine_bits;
+                const u32 at = atomicAdd(&lcnt[bin], 1u);
+                u32 name = (u32)(base + t + (u64)j * 512);
+                if (entry_point) { name = entry_point[name]; if (name >= n_points) name = 0xffffffu; }
+                stage_val[at] = name | (((a - 1) & fine_mask) << 24) | ((d & 0x8000u) << 16);
+                stage_bin[at] = (unsigned char)bin;
+            }
+        }
+        __syncthreads();
+        const u32 total = total_sh;
+        for (u32 k = t; k < total; k += 512) {
+            const u32 pos = delta[stage_bin[k]] + k;               // (32-bit on purpose: delta = cursor - start may have wrapped)
+            if (pos < cap) tmp[pos] = stage_val[k];
+        }
+        __syncthreads();
+        if (t < nb) { gcur[t] += own; lcnt[t] = 0; }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_msm_fine_sort_staged(const u32 *__restrict__ tmp, const u32 *__restrict__ coarse_off, msm_plan p, u32 *__restrict__ offsets,
+                                                              u32 *__restrict__ sorted, u64 cap) {
+    wave_priority_high();
+    constexpr u32 PER = 2 * STAGE_PER_THREAD, SUB = 256 * PER;
+    __shared__ u32 stage_val[SUB];
+    __shared__ unsigned char stage_b[SUB];
+    __shared__ u32 cur[128], lcnt[128], scan[128], delta[128];
+    __shared__ u32 total_sh;
+    const u32 bin = blockIdx.x, w = blockIdx.y, nb = p.B >> p.fine_bits, F = 1u << p.fine_bits, t = threadIdx.x;
+    const u32 s = coarse_off[(u64)w * nb + bin], e = coarse_off[(u64)w * nb + bin + 1];
+    if (t < F) lcnt[t] = 0;
+    __syncthreads();
+    // the bin's buckets: counts over the whole bin, their offsets
+    for (u32 k0 = s + t; k0 < e; k0 += SORT_UNROLL * blockDim.x) {
+        u32 v[SORT_UNROLL];
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) { u32 k = k0 + j * blockDim.x; v[j] = k < e ? tmp[k] : 0xffffffffu; }
+#pragma unroll
+        for (u32 j = 0; j < SORT_UNROLL; j++) if (k0 + j * blockDim.x < e) atomicAdd(&lcnt[(v[j] >> 24) & 127u], 1u);
+    }
+    __syncthreads();
+    {
+        u32 own, start;
+        staged_scan(lcnt, scan, F, t, own, start);
+        if (t < F) { offsets[(u64)w * p.B + (u64)bin * F + t] = s + start; cur[t] = s + start; lcnt[t] = 0; }
+        if (t == 0 && bin == nb - 1 && w == p.W - 1) offsets[(u64)p.W * p.B] = e;
+        __syncthreads();
+    }
+    for (u32 base = s; base < e; base += SUB) {
+        u32 v[PER];
+#pragma unroll
+        for (u32 j = 0; j < PER; j++) { const u32 k = base + t + j * 256; v[j] = k < e ? tmp[k] : 0u; }
+#pragma unroll
+        for (u32 j = 0; j < PER; j++) if (base + t + j * 256 < e) atomicAdd(&lcnt[(v[j] >> 24) & 127u], 1u);
+        __syncthreads();
+        u32 own, start;
+        staged_scan(lcnt, scan, F, t, own, start);
+        if (t < F) { delta[t] = cur[t] - start; lcnt[t] = start; }
+        if (t == F - 1) total_sh = start + own;
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < PER; j++) {
+            if (base + t + j * 256 < e) {
+                const u32 b = (v[j] >> 24) & 127u;
+                const u32 at = atomicAdd(&lcnt[b], 1u);
+                stage_val[at] = v[j] & 0x80ffffffu;
+                stage_b[at] = (unsigned char)b;
+            }
+        }
+        __syncthreads();
+        const u32 total = total_sh;
+        for (u32 k = t; k < total; k += 256) {
+            const u32 pos = delta[stage_b[k]] + k;
+            if (pos < cap) sorted[pos] = stage_val[k];
+        }
+        __syncthreads();
+        if (t < F) { cur[t] += own; lcnt[t] = 0; }
+        __syncthreads();
+    }
+}
+
 // Thread per chunk [t*M, (t+1)*M) of the bucket-sorted entries.  term_point (nullable): term index ->
 // record index in niels[]; n_points bounds the gather.  (When the sort already wrote record indices, msm_launch passes no
 // map and the record count as n.)  chunk_sums[2t] = partial sum of the bucket that
@@ -799,8 +929,15 @@ hipError_t msm_launch(hipStream_t st, const u32 *d_scalars, const u32 *d_niels, 
         MARK("msm_scan");
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(1), dim3(1024), 0, st, ws.tile_hist, n_bins, q.B, tiles, ws.coarse);
         MARK("msm_scatter");
-        hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap, entry_point, (u32)n_points);
-        hipLaunchKernelGGL(k_msm_fine_sort, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);
+        // (XHE_MSM_SORT_STAGED=0: the forms that write every entry straight to its place, for tests and comparisons)
+        const char *sort_env = setting("XHE_MSM_SORT_STAGED");
+        if (sort_env && sort_env[0] == '0') {
+            hipLaunchKernelGGL(k_msm_coarse_scatter, dim3(tiles, p.W), dim3(512), q.B * 4, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap, entry_point, (u32)n_points);
+            hipLaunchKernelGGL(k_msm_fine_sort, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);
+        } else {
+            hipLaunchKernelGGL(k_msm_coarse_scatter_staged, dim3(tiles, p.W), dim3(512), 0, st, digits, n, p, tiles, ws.tile_hist, ws.coarse, ws.tmp, sorted_cap, entry_point, (u32)n_points);
+            hipLaunchKernelGGL(k_msm_fine_sort_staged, dim3(q.B, p.W), dim3(256), 0, st, ws.tmp, ws.coarse, p, ws.offsets, ws.sorted, sorted_cap);
+        }
     }
     MARK("msm_wait_points");
     for (hipEvent_t ev : deps.points_ready) if (ev && (e = hipStreamWaitEvent(st, ev, 0)) != hipSuccess) return e;
