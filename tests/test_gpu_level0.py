@@ -90,6 +90,28 @@ def test_msm_skewed_digits(engine, oracle, n, kind):
     assert ident == bool(idf[0])
 
 
+@pytest.mark.parametrize("n,kind", [(262144, "random"), (210000, "equal"), (210000, "small")])
+def test_msm_two_pass_sort_without_lds_staging(engine, oracle, switch, n, kind):
+    """The two-pass bucket sort in its direct form (every entry written where its counter says, XHE_MSM_SORT_STAGED=0) and in the
+    default form (entries ordered inside LDS, written out as runs) give the oracle's sum."""
+    r = rng(9000 + n)
+    pool = _oracle_points(oracle, r, 32)
+    pts = b"".join(pool[r.randrange(32)] for _ in range(n))
+    if kind == "equal":
+        vals = [r.randrange(S.L)] * n
+    elif kind == "small":
+        vals = [r.randrange(4) for _ in range(n)]
+    else:
+        vals = [r.randrange(S.L) for _ in range(n)]
+    scal = b"".join(le32(v) for v in vals)
+    o, idf = buf(32), buf(1)
+    assert oracle.xo_msm_vartime(n, scal, pts, o, idf) == 0
+    for staged in ("0", None):
+        switch("XHE_MSM_SORT_STAGED", staged)
+        got, ident = engine.msm_vartime(scal, pts)
+        assert got == bytes(o) and ident == bool(idf[0]), staged
+
+
 def test_msm_identity_and_cancellation(engine, oracle):
     r = rng(77)
     pool = _oracle_points(oracle, r, 8)

@@ -174,8 +174,12 @@ int32_t xhe::ensure_tables(xhe_ctx *ctx, u32 cap) {
 
 static int32_t batch_verify_impl(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict, const uint8_t seed[32]);
 static constexpr int32_t ENQUEUE_TABLES_BUSY = 2;
+// The ledger a part of a batch verified in parts starts from: the call's ledger array on the device, valid once `after` has fired
+// (null: valid already).  The part copies it into its byte buffer on its ledger stream, in front of the decode of the ledger's
+// slots - the only work of the part that has to wait for the part in front.
+struct ledger_handover { const void *src; size_t bytes; hipEvent_t after; };
 static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side, bool may_block = true, int lane_or_none = -1,
-                                    u32 *carry_ledger = nullptr);
+                                    u32 *carry_ledger = nullptr, const ledger_handover *handover = nullptr);
 static int32_t batch_verify_finish(xhe_ctx *ctx, xhe_batch *B, xhe_verdict *verdict);
 
 extern "C" {
@@ -980,7 +984,9 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
             const host_batch &hb = B->hb;
             // the stream this part's ledger inputs are decoded on: side stream 1 with lanes (batch_verify_enqueue), else side stream 0
             hipStream_t s_in = lanes ? ctx->side[1] : s0;
-            if (k > 0 && in->n_balances) {
+            ledger_handover ho{ledger.p, 64 * in->n_balances, (overlap && in_flight >= 0) ? parts[(size_t)in_flight].B->ev_carried : nullptr};
+            const bool hand_inside = lanes && k > 0 && in->n_balances;      // with lanes the copy is part of the part's own launch sequence
+            if (k > 0 && in->n_balances && !hand_inside) {
                 // the ciphertexts this part starts from, behind its upload, behind the hand-over of the part in front (a part that
                 // has finished has handed over) and in front of its ledger decode
                 hipError_t e = hipStreamWaitEvent(s_in, B->ev_uploaded, 0);
@@ -993,10 +999,11 @@ static int32_t verify_batch_split(xhe_ctx *ctx, const uint8_t *records, const ui
             u8 seed[32]; memcpy(seed, rng_seed, 32); seed[31] ^= (u8)k; seed[30] ^= (u8)(k >> 8);      // independent batch factors per part
             const int lane = lanes ? (int)(n_enqueued & 1) : -1;
             u32 *carry = overlap ? ledger.as<u32>() : nullptr;
-            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, in_flight < 0, lane, carry);
+            if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, in_flight < 0, lane, carry, hand_inside ? &ho : nullptr);
             if (rc == ENQUEUE_TABLES_BUSY) {
                 rc = finish_part((u32)in_flight); in_flight = -1;
-                if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, true, lane, carry);
+                ho.after = nullptr;
+                if (rc == 0) rc = batch_verify_enqueue(ctx, B, seed, overlap, true, lane, carry, hand_inside ? &ho : nullptr);
             }
             if (rc == 0) n_enqueued++;
             at(k, "enqueued");
@@ -1228,7 +1235,7 @@ int32_t xhe_verify_batches(xhe_ctx *ctx, uint64_t n_batches, const xhe_batch_arg
 // lane_or_none = -1: no lanes (a single verification, or a run of independent batches); carry_ledger: the device array of the whole
 // ledger's ciphertexts that a part writes the slots it used into, right behind its ledger scan (B->ev_carried fires then).
 static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t seed[32], bool setup_on_side /* one of the parts of a batch verified in parts */, bool may_block,
-                                    int lane_or_none, u32 *carry_ledger) {
+                                    int lane_or_none, u32 *carry_ledger, const ledger_handover *handover) {
     const host_batch &hb = B->hb;
     // XHE_ONE_STREAM=1 (diagnostics): everything on the main stream, so that a kernel trace shows every kernel's stand-alone time
     const bool one_stream = setting("XHE_ONE_STREAM") != nullptr;
@@ -1315,9 +1322,16 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     hipStream_t ssig = one_stream ? st : (own_sig_stream ? ctx->side[2] : s1);
     HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_setup, 0));
     if (early_on_s1) {
+        // the transfers' ciphertexts on side stream 1; the ledger's slots (the tail of the list) on the ledger stream, behind the
+        // hand-over from the part in front: nothing else of this part waits for that part's ledger
         HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
-        launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
+        launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.early_end, hb.n_static, pts, ok);
         HIPCHK(ctx, hipEventRecord(ctx->ev_early, s1));
+        if (handover && handover->bytes) {
+            if (handover->after) HIPCHK(ctx, hipStreamWaitEvent(s0, handover->after, 0));
+            HIPCHK(ctx, hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, handover->src, handover->bytes, hipMemcpyDeviceToDevice, s0));
+        }
+        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>() + hb.early_end, hb.n_early - hb.early_end, hb.n_static, pts, ok);
         HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_early, 0));
     } else {
         HIPCHK(ctx, tm.open("decode_first", s0));
