@@ -435,13 +435,13 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     std::pmr::vector<u32> ops_count(mr);                        // per used slot: operations so far (slot_pos: position of its initial C, D = +1)
     std::unordered_map<u64, u32> signer_pos;           // byte offset of a signer key -> position
     std::unordered_map<u32, u32> pos_keyslot;          // position of a signer / unknown-source key -> position in sig_keys
-    struct ms_cfg { std::vector<u64> signer_off; u32 threshold; };
+    struct ms_cfg { u64 first_off; u32 n_signers, threshold; };       // signer k's key: 32 bytes at first_off + 32 k (the ledger view's and a record's are both contiguous)
     std::vector<ms_cfg> cfgs;
+    cfgs.reserve(lv.n_multisig + 16);
     std::pmr::vector<int32_t> cfg_of(lv.n_accounts, -1, mr);
     for (u64 i = 0; i < lv.n_multisig; i++) {
-        ms_cfg c; c.threshold = lv.multisig_threshold[i];
-        for (u32 j = lv.multisig_offsets[i]; j < lv.multisig_offsets[i + 1]; j++) c.signer_off.push_back(hb.signers_base + 32ull * j);
-        cfg_of[lv.multisig_account[i]] = (int32_t)cfgs.size(); cfgs.push_back(c);
+        cfg_of[lv.multisig_account[i]] = (int32_t)cfgs.size();
+        cfgs.push_back({hb.signers_base + 32ull * lv.multisig_offsets[i], lv.multisig_offsets[i + 1] - lv.multisig_offsets[i], lv.multisig_threshold[i]});
     }
     auto account_position = [&](u32 a) { if (acc_pos[a] == NONE) acc_pos[a] = new_shared(hb.keys_base + 32ull * a, 2); return acc_pos[a]; };
     auto touch_slot = [&](u32 bal, bool *fresh) {
@@ -510,8 +510,8 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                     for (u32 k = 0; k < t.n_multisig; k++) {
                         const u8 idx = t.ms_entry(k)[0];
                         for (u32 j = 0; j < t.n_multisig; j++) if (j != k && t.ms_entry(j)[0] == idx) raise(errkey(ST_MULTISIG, k, 1, XHE_ERR_FORMAT));
-                        if (idx < cfg.signer_off.size()) {
-                            const u64 koff = cfg.signer_off[idx];
+                        if (idx < cfg.n_signers) {
+                            const u64 koff = cfg.first_off + 32ull * idx;
                             auto sp = signer_pos.find(koff);
                             const u32 kp = sp != signer_pos.end() ? sp->second : (signer_pos[koff] = new_shared(koff, 2));
                             ms_entries.push_back({koff, (u32)i, k, kp, keyslot_of_pos(kp)});
@@ -548,9 +548,7 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 else if (sa != NONE) {
                     if (t.n_items == 0) cfg_of[sa] = -1;
                     else {
-                        ms_cfg c; c.threshold = t.payload()[0];
-                        for (u32 k = 0; k < t.n_items; k++) c.signer_off.push_back(rec + t.payload_off + 1 + 32ull * k);
-                        cfg_of[sa] = (int32_t)cfgs.size(); cfgs.push_back(c);
+                        cfg_of[sa] = (int32_t)cfgs.size(); cfgs.push_back({rec + t.payload_off + 1, t.n_items, t.payload()[0]});
                     }
                     hb.multisig_set_by[sa] = (int64_t)i; hb.multisig_updated = true;
                 }

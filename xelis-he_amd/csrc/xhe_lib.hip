@@ -32,12 +32,16 @@ static constexpr size_t MSM_STATIC_BYTES = 12ull << 20;
 static __device__ __align__(256) unsigned char scratch[MSM_STATIC_BYTES];
 
 static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory per context, at most
-// xhe_verify_batch cuts a batch whose records reach twice this size into parts of about this size, at most SPLIT_PARTS_MAX
-// (verify_batch_split below).  Measured on 100 000 transactions of 8 transfers (390 MB): one piece 39-41 ms, 4 parts 31 ms,
-// 6 parts 27-28 ms, 8 parts 28 ms, 10 parts 31 ms -- every part adds fixed host work to the one uploader thread and a latency-bound
-// head and tail on the device; batches of one-transfer transactions (125 000: 178 MB) want parts of their own size class, hence
-// the part size below rather than a sixth of the largest shape.
-static constexpr u64 SPLIT_PART_BYTES = 40ull << 20;
+// xhe_verify_batch cuts a batch into parts (verify_batch_split below) by the size of its records and by the number of its
+// transactions, whichever asks for more, at most SPLIT_PARTS_MAX: the host's ordered walk costs per transaction, the copies and the
+// device's work per byte.  Every part adds fixed host work to the one uploader thread and a latency-bound head and tail on the
+// device (0.6-0.8 ms).  Measured, one call from host buffers: 100 000 transactions of 8 transfers (390 MB) in one piece 39-41 ms,
+// 4 parts 31 ms, 6 parts 25.5-26 ms, 8 parts 28 ms; 100 000 mixed transactions (100 MB) in 3 parts 27.0 ms, 5-6 parts 24.0 ms;
+// 125 000 one-transfer transactions (170 MB) in 4 parts 17.2 ms, 5-6 parts 16.2 ms; 40 000 of those in one piece 7.7 ms, 3 parts
+// 6.6 ms; 20 000 transactions of 8 transfers (78 MB) in one piece 8.0 ms, 2-3 parts 7.5 ms; 20 000 and fewer one-transfer
+// transactions are fastest in one piece.
+static constexpr u64 SPLIT_PART_BYTES = 32ull << 20;
+static constexpr u64 SPLIT_PART_TXS = 13000;
 static constexpr u64 SPLIT_PARTS_MAX = 6;
 static constexpr u32 VERDICT_SLOTS = 4;              // verifications whose verdict words may be on their way to the host at once
 // From this batch size on the signatures get a stream of their own and start beside the transcripts (measured on the
@@ -788,7 +792,7 @@ static u32 split_parts_for(u64 n_txs, const u64 *offsets, const xhe_ledger_view 
     const u64 ledger_bytes = 32 * in->n_accounts + 64 * in->n_balances + 32 * n_signers;
     // every part carries the whole ledger view: not worth it for a view that is large beside the records
     if (ledger_bytes > rec_bytes / 16) return 1;
-    const u64 parts = rec_bytes / SPLIT_PART_BYTES;
+    const u64 parts = std::max(rec_bytes / SPLIT_PART_BYTES, n_txs / SPLIT_PART_TXS);
     return parts < 2 ? 1u : (u32)std::min<u64>(std::min<u64>(parts, SPLIT_PARTS_MAX), n_txs);
 }
 
