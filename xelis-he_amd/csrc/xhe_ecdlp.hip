@@ -330,8 +330,10 @@ struct xhe_ecdlp_table {
     xhe_ctx *ctx = nullptr;
     u32 b = 0, slot_bits = 0;
     ge b4;                                   // 4 G (host copy)
-    dev_buf slots, b4_dev;
+    dev_buf slots, b4_dev, offset_dev;       // the table; 4 G; -(2^b) 4 G (what an instance's walk starts from, beside 4 P)
     dev_buf gt; u32 gt_max_bits = 0; u64 gt_steps = 0;         // the giant-step points of the last max_bits asked for
+    dev_buf ws;                                                // one block for a call's temporaries, kept between calls (grown when a call needs more)
+    std::vector<unsigned long long> host_amounts; std::vector<u8> host_status;
     xhe_ecdlp_stats last{0, 0, 0.0, 0};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -388,11 +390,14 @@ int32_t xhe_ecdlp_table_create(xhe_ctx *ctx, uint32_t table_bits, xhe_ecdlp_tabl
     t->ctx = ctx; t->b = table_bits; t->slot_bits = table_bits + 1;
     t->b4 = ge_double(ge_double(host_basepoint()));
     const u64 n_slots = 1ull << t->slot_bits;
-    struct release_on_error { xhe_ecdlp_table *t; bool armed = true; ~release_on_error() { if (armed) { t->slots.release(); t->b4_dev.release(); } } } guard{t.get()};
+    struct release_on_error { xhe_ecdlp_table *t; bool armed = true; ~release_on_error() { if (armed) { t->slots.release(); t->b4_dev.release(); t->offset_dev.release(); } } } guard{t.get()};
     HIPCHK(ctx, t->slots.reserve(n_slots * 8));
     HIPCHK(ctx, t->b4_dev.reserve(128));
     u32 packed[32]; ge_store(packed, t->b4);
     HIPCHK(ctx, hipMemcpyAsync(t->b4_dev.p, packed, 128, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, t->offset_dev.reserve(128));
+    u32 packed_offset[32]; ge_store(packed_offset, ge_neg(host_mul_u64(t->b4, 1ull << table_bits)));
+    HIPCHK(ctx, hipMemcpyAsync(t->offset_dev.p, packed_offset, 128, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_ec_fill64, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, t->slots.as<unsigned long long>(), n_slots, EC_EMPTY);
     // j = chunk * per + k: the chunk starts (chunk * per) B4 play the instances, the points k B4 the table
     const u32 per = 1u << std::min<u32>(table_bits, 10);
@@ -426,7 +431,7 @@ void xhe_ecdlp_table_free(xhe_ecdlp_table *t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    t->slots.release(); t->b4_dev.release(); t->gt.release();
+    t->slots.release(); t->b4_dev.release(); t->offset_dev.release(); t->gt.release(); t->ws.release();
     for (hipEvent_t e : t->ev) if (e) (void)hipEventDestroy(e);
     delete t;
 }
@@ -450,37 +455,46 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
         if (int32_t rc = make_affine_multiples(ctx, st, S, steps, true, true, t->gt)) return rc;
         t->gt_max_bits = max_bits; t->gt_steps = steps;
     }
-    dev_buf in_dev, secret_dev, offset_dev, four_p, inst, status, amt, scratch, steps_done, cand;
-    struct release { std::vector<dev_buf *> v; ~release() { for (dev_buf *d : v) d->release(); } } temporaries{{&in_dev, &secret_dev, &offset_dev, &four_p, &inst, &status, &amt, &scratch, &steps_done, &cand}};
+    // the call's temporaries are 256-byte aligned ranges of the table's workspace block: no allocation from the second call on
     const u64 in_bytes = (mode ? 64ull : 32ull) * n;
-    HIPCHK(ctx, in_dev.reserve(in_bytes)); HIPCHK(ctx, offset_dev.reserve(128)); HIPCHK(ctx, four_p.reserve(128 * n)); HIPCHK(ctx, inst.reserve(EC_ENTRY_WORDS * 4 * n));
-    HIPCHK(ctx, status.reserve(n)); HIPCHK(ctx, amt.reserve(8 * n)); HIPCHK(ctx, steps_done.reserve(64)); HIPCHK(ctx, secret_dev.reserve(64));
+    ec_bsgs_args a{};
+    const char *occ_env = setting("XHE_ECDLP_OCC");
+    const bool occ3 = !(occ_env && occ_env[0] == '4');
+    const u64 grid_lanes = ec_grid_lanes(ctx, occ3 ? 3 : 4);
+    // steps per item (= per shared inversion): 128 when that still makes at least two items per resident lane, else shorter items
+    // down to 32 - a short walk (few instances, or a large table) is bound by the length of a lane's chain, not by its arithmetic
+    a.K = (u32)std::min<u64>(EC_CHUNK, steps);
+    while (a.K > 32 && n * ((steps + a.K - 1) / a.K) < 2 * grid_lanes) a.K >>= 1;
+    a.n_items = n * ((steps + a.K - 1) / a.K);
+    a.n_lanes = std::min<u64>((a.n_items + 255) / 256 * 256, grid_lanes);
+    // (nearly) every item in flight at once: little can drop out early, candidates go through a list and a kernel of their own
+    // instead of stalling their wavefronts with a confirmation each
+    const bool listed = a.n_items <= 4 * a.n_lanes;
+    const u32 cand_cap = (u32)(8 * n + 4096);
+    dev_buf in_dev, secret_dev, four_p, inst, status, amt, scratch, steps_done, cand;
+    {
+        struct want { dev_buf *buf; u64 bytes; };
+        const want wants[] = {{&in_dev, in_bytes}, {&secret_dev, 64}, {&four_p, 128 * n}, {&inst, EC_ENTRY_WORDS * 4ull * n}, {&status, n}, {&amt, 8 * n},
+                              {&scratch, a.n_lanes * a.K * 40ull}, {&steps_done, 64}, {&cand, listed ? 16ull * cand_cap : 0}};
+        u64 total = 0;
+        for (const want &w : wants) total += (std::max<u64>(w.bytes, 64) + 255) & ~255ull;
+        HIPCHK(ctx, t->ws.reserve(total));
+        u64 off = 0;
+        for (const want &w : wants) { const u64 sz = (std::max<u64>(w.bytes, 64) + 255) & ~255ull; w.buf->point_at(t->ws.p, off, sz); off += sz; }
+    }
     HIPCHK(ctx, hipMemcpyAsync(in_dev.p, in, in_bytes, hipMemcpyHostToDevice, st));
     u32 secret_words[8] = {0};
     if (mode == 1) { for (int k = 0; k < 8; k++) secret_words[k] = (u32)secret32[4 * k] | ((u32)secret32[4 * k + 1] << 8) | ((u32)secret32[4 * k + 2] << 16) | ((u32)secret32[4 * k + 3] << 24); }
     HIPCHK(ctx, hipMemcpyAsync(secret_dev.p, secret_words, 32, hipMemcpyHostToDevice, st));
-    u32 packed[32]; ge_store(packed, ge_neg(host_mul_u64(t->b4, 1ull << b)));
-    HIPCHK(ctx, hipMemcpyAsync(offset_dev.p, packed, 128, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_ec_fill64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, amt.as<unsigned long long>(), n, EC_EMPTY);
     hipLaunchKernelGGL(k_ec_fill64, dim3(1), dim3(64), 0, st, steps_done.as<unsigned long long>(), (u64)3, 0ull);     // steps walked, item counter, candidate counter
-    hipLaunchKernelGGL(k_ec_prepare, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in_dev.as<u8>(), (u32)n, mode, secret_dev.as<u32>(), offset_dev.as<u32>(), four_p.as<u32>(), inst.as<u32>(),
+    hipLaunchKernelGGL(k_ec_prepare, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in_dev.as<u8>(), (u32)n, mode, secret_dev.as<u32>(), t->offset_dev.as<u32>(), four_p.as<u32>(), inst.as<u32>(),
                        status.as<u8>());
-    ec_bsgs_args a{};
-    a.K = (u32)std::min<u64>(EC_CHUNK, steps);
-    const char *occ_env = setting("XHE_ECDLP_OCC");
-    const bool occ3 = !(occ_env && occ_env[0] == '4');
-    const u64 grid_lanes = ec_grid_lanes(ctx, occ3 ? 3 : 4);
-    a.inst = inst.as<u32>(); a.n_inst = n; a.gt = t->gt.as<u32>(); a.steps = steps; a.n_items = n * ((steps + a.K - 1) / a.K);
-    a.n_lanes = std::min<u64>((a.n_items + 255) / 256 * 256, grid_lanes);
-    HIPCHK(ctx, scratch.reserve(a.n_lanes * a.K * 40));
+    a.inst = inst.as<u32>(); a.n_inst = n; a.gt = t->gt.as<u32>(); a.steps = steps;
     a.scratch = scratch.as<u32>(); a.slots = t->slots.as<unsigned long long>(); a.slot_bits = t->slot_bits;
     a.amounts = amt.as<unsigned long long>(); a.four_p = four_p.as<u32>(); a.b4_xyzt = t->b4_dev.as<u32>(); a.b = b; a.max_bits = max_bits;
     a.steps_done = steps_done.as<unsigned long long>(); a.next_item = steps_done.as<unsigned long long>() + 1;
-    // every item in flight at once: nothing can drop out early, candidates go through a list and a kernel of their own
-    const bool listed = a.n_items <= a.n_lanes;
-    const u32 cand_cap = (u32)(8 * n + 4096);
     if (listed) {
-        HIPCHK(ctx, cand.reserve(16ull * cand_cap));
         a.cand = cand.as<u32>(); a.cand_cap = cand_cap; a.cand_count = (u32 *)(steps_done.as<unsigned long long>() + 2);
     }
     HIPCHK(ctx, hipEventRecord(t->ev[0], st));
@@ -495,8 +509,8 @@ static int32_t ecdlp_run(xhe_ecdlp_table *t, const uint8_t *in, uint64_t n, uint
     }
     HIPCHK(ctx, hipEventRecord(t->ev[1], st));
     HIPCHK(ctx, hipGetLastError());
-    std::vector<unsigned long long> host(n);
-    std::vector<u8> host_status(n);
+    std::vector<unsigned long long> &host = t->host_amounts; std::vector<u8> &host_status = t->host_status;
+    if (host.size() < n) { host.resize(n); host_status.resize(n); }
     unsigned long long done = 0;
     HIPCHK(ctx, hipMemcpyAsync(host.data(), amt.p, 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(host_status.data(), status.p, n, hipMemcpyDeviceToHost, st));
