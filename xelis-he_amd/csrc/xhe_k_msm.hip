@@ -82,6 +82,7 @@ msm_plan msm_make_plan(u64 n) {
 
 static constexpr u32 SCAN_TILE = 1024;       // counters per workgroup of the bucket-offset scan
 static constexpr u32 MERGE_SPAN_MAX = 8;     // a bucket cut into more chunks than this is reduced by a workgroup
+static constexpr u32 SUM_WORDS = 40;         // words of a bucket or chunk sum in memory (sum_store / sum_load below)
 
 static inline u64 msm_sort_tiles(u64 n, const msm_plan &p) { return n ? (n + p.tile - 1) / p.tile : 1; }
 static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return (e + p.M - 1) / p.M + 1; }
@@ -89,9 +90,9 @@ static inline u64 msm_chunks(u64 n, const msm_plan &p) { u64 e = n * p.W; return
 msm_ws_bytes msm_workspace_bytes(u64 n, const msm_plan &p) {
     u64 nb = (u64)p.W * p.B, entries = n * p.W, chunks = msm_chunks(n, p);
     msm_ws_bytes b;
-    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.tile_hist = nb * msm_sort_tiles(n, p) * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * 128;
+    b.hist = nb * 4; b.offsets = (nb + 1) * 4; b.tile_hist = nb * msm_sort_tiles(n, p) * 4; b.sorted = (entries ? entries : 1) * 4; b.buckets = nb * (SUM_WORDS * 4ull);
     b.digits = (entries ? entries : 1) * 2;
-    b.chunk_sums = chunks * 2 * 128; b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
+    b.chunk_sums = chunks * 2 * (SUM_WORDS * 4ull); b.big_list = (chunks / MERGE_SPAN_MAX + 16) * 4;
     b.segs = (u64)p.W * p.S * 2 * 128 + (nb / SCAN_TILE + 1) * 4; b.wins = (u64)p.W * 128;          // segs doubles as the scan's tile sums
     b.tmp = p.fine_bits ? b.sorted : 64; b.coarse = ((u64)p.W * (p.B >> p.fine_bits) + 1) * 4 + 64;
     return b;
@@ -552,6 +553,30 @@ __global__ void __launch_bounds__(256) k_msm_fine_sort_staged(const u32 *__restr
     }
 }
 
+// Bucket sums and the chunks' partial sums in memory: the four coordinates as the ten limbs the arithmetic leaves them in (40
+// words), not as 32 canonical bytes each.  A bucket border inside a wavefront is paid by all of its lanes, and packing a point
+// costs about 400 instructions; with a few dozen entries per bucket (a batch verified in parts) nearly every iteration of a
+// wavefront has a lane at a border.
+__device__ __forceinline__ void sum_store(u32 *__restrict__ dst, const ge &p) {
+    uint4 *d = (uint4 *)dst;
+    const u32 w[40] = {p.X.v[0], p.X.v[1], p.X.v[2], p.X.v[3], p.X.v[4], p.X.v[5], p.X.v[6], p.X.v[7], p.X.v[8], p.X.v[9],
+                       p.Y.v[0], p.Y.v[1], p.Y.v[2], p.Y.v[3], p.Y.v[4], p.Y.v[5], p.Y.v[6], p.Y.v[7], p.Y.v[8], p.Y.v[9],
+                       p.Z.v[0], p.Z.v[1], p.Z.v[2], p.Z.v[3], p.Z.v[4], p.Z.v[5], p.Z.v[6], p.Z.v[7], p.Z.v[8], p.Z.v[9],
+                       p.T.v[0], p.T.v[1], p.T.v[2], p.T.v[3], p.T.v[4], p.T.v[5], p.T.v[6], p.T.v[7], p.T.v[8], p.T.v[9]};
+#pragma unroll
+    for (int j = 0; j < 10; j++) d[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+__device__ __forceinline__ ge sum_load(const u32 *__restrict__ src) {
+    const uint4 *s4 = (const uint4 *)src;
+    u32 w[40];
+#pragma unroll
+    for (int j = 0; j < 10; j++) { const uint4 v = s4[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    ge p;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+    return p;
+}
+
 // Thread per chunk [t*M, (t+1)*M) of the bucket-sorted entries.  term_point (nullable): term index ->
 // record index in niels[]; n_points bounds the gather.  (When the sort already wrote record indices, msm_launch passes no
 // map and the record count as n.)  chunk_sums[2t] = partial sum of the bucket that
@@ -595,7 +620,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate_regs(const u32 *__res
         u32 e_next = 0, raw_next[24]; bool valid_next = false;
         if (k + 1 < stop) fetch(k + 1, e_next, valid_next, raw_next);
         if (k >= bend) {                              // bucket b ended exactly at k
-            ge_store(began_before ? chunk_sums + 64ull * t : bucket_sums + 32ull * b, acc);
+            sum_store(began_before ? chunk_sums + 2ull * SUM_WORDS * t : bucket_sums + (u64)SUM_WORDS * b, acc);
             acc = ge_identity(); began_before = false;
             do { b++; bend = offsets[b + 1]; } while (k >= bend);     // b < n_buckets since k < total
         }
@@ -608,10 +633,10 @@ __global__ void __launch_bounds__(256, 2) k_msm_accumulate_regs(const u32 *__res
         for (int j = 0; j < 24; j++) raw_cur[j] = raw_next[j];
     }
     u32 *dst;
-    if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
-    else if (bend <= stop) dst = bucket_sums + 32ull * b;            // the bucket is complete inside the chunk
-    else dst = chunk_sums + 64ull * t + 32;
-    ge_store(dst, acc);
+    if (began_before) dst = chunk_sums + 2ull * SUM_WORDS * t;       // also when the bucket runs on past the chunk
+    else if (bend <= stop) dst = bucket_sums + (u64)SUM_WORDS * b;   // the bucket is complete inside the chunk
+    else dst = chunk_sums + 2ull * SUM_WORDS * t + SUM_WORDS;
+    sum_store(dst, acc);
 }
 
 // The accumulation with the prefetched record held in LDS instead of in registers (k_msm_accumulate_regs above is the register
@@ -669,7 +694,7 @@ k_msm_accumulate(const u32 *__restrict__ niels, u64 n_points, const u32 *__restr
         const bool more = k + 1 < stop;
         const u32 e_next = more ? sorted[k + 1] : 0u;
         if (k >= bend) {                              // bucket b ended exactly at k
-            ge_store(began_before ? chunk_sums + 64ull * t : bucket_sums + 32ull * b, acc);
+            sum_store(began_before ? chunk_sums + 2ull * SUM_WORDS * t : bucket_sums + (u64)SUM_WORDS * b, acc);
             acc = ge_identity(); began_before = false;
             do { b++; bend = offsets[b + 1]; } while (k >= bend);     // b < n_buckets since k < total
         }
@@ -693,10 +718,10 @@ k_msm_accumulate(const u32 *__restrict__ niels, u64 n_points, const u32 *__restr
         e_cur = e_next; valid_cur = valid_next;
     }
     u32 *dst;
-    if (began_before) dst = chunk_sums + 64ull * t;                  // also when the bucket runs on past the chunk
-    else if (bend <= stop) dst = bucket_sums + 32ull * b;            // the bucket is complete inside the chunk
-    else dst = chunk_sums + 64ull * t + 32;
-    ge_store(dst, acc);
+    if (began_before) dst = chunk_sums + 2ull * SUM_WORDS * t;       // also when the bucket runs on past the chunk
+    else if (bend <= stop) dst = bucket_sums + (u64)SUM_WORDS * b;   // the bucket is complete inside the chunk
+    else dst = chunk_sums + 2ull * SUM_WORDS * t + SUM_WORDS;
+    sum_store(dst, acc);
 }
 
 // thread per bucket: empty buckets get the identity, buckets inside one chunk are already final, the others
@@ -707,7 +732,7 @@ __global__ void __launch_bounds__(256, 2) k_msm_merge(const u32 *__restrict__ of
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_buckets) return;
     u32 lo = offsets[g], hi = offsets[g + 1];
-    if (lo == hi) { ge_store(bucket_sums + 32ull * g, ge_identity()); return; }
+    if (lo == hi) { sum_store(bucket_sums + (u64)SUM_WORDS * g, ge_identity()); return; }
     u32 c0 = lo / M, c1 = (hi - 1) / M;
     if (c0 == c1) return;
     if (c1 - c0 > MERGE_SPAN_MAX) {
@@ -715,9 +740,9 @@ __global__ void __launch_bounds__(256, 2) k_msm_merge(const u32 *__restrict__ of
         if (pos < big_cap) big_list[1 + pos] = g;
         return;
     }
-    ge acc = ge_load(chunk_sums + 64ull * c0 + 32);        // the first chunk holds it as its trailing partial
-    for (u32 c = c0 + 1; c <= c1; c++) acc = ge_add(acc, ge_load(chunk_sums + 64ull * c));
-    ge_store(bucket_sums + 32ull * g, acc);
+    ge acc = sum_load(chunk_sums + 2ull * SUM_WORDS * c0 + SUM_WORDS);        // the first chunk holds it as its trailing partial
+    for (u32 c = c0 + 1; c <= c1; c++) acc = ge_add(acc, sum_load(chunk_sums + 2ull * SUM_WORDS * c));
+    sum_store(bucket_sums + (u64)SUM_WORDS * g, acc);
 }
 
 // wavefront per deferred bucket (grid-stride over the list): the lanes add the chunk partials with stride 64 and fold with
@@ -733,15 +758,15 @@ __global__ void __launch_bounds__(256, 2) k_msm_merge_big(const u32 *__restrict_
         u32 lo = offsets[g], hi = offsets[g + 1];
         u32 c0 = lo / M, c1 = (hi - 1) / M;
         ge acc = ge_identity();
-        if (lane == 0) acc = ge_load(chunk_sums + 64ull * c0 + 32);       // the first chunk holds the bucket as its trailing partial
-        for (u32 c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, ge_load(chunk_sums + 64ull * c));
+        if (lane == 0) acc = sum_load(chunk_sums + 2ull * SUM_WORDS * c0 + SUM_WORDS);       // the first chunk holds the bucket as its trailing partial
+        for (u32 c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, sum_load(chunk_sums + 2ull * SUM_WORDS * c));
 #pragma unroll
         for (u32 d = 32; d >= 1; d >>= 1) {
             ge o = ge_shfl_down(acc, d);
             ge sum = ge_add(acc, o);
             acc = ge_select(acc, sum, lane < d);
         }
-        if (lane == 0) ge_store(bucket_sums + 32ull * g, acc);
+        if (lane == 0) sum_store(bucket_sums + (u64)SUM_WORDS * g, acc);
     }
 }
 
@@ -781,7 +806,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const u32 *__restric
     ge run = ge_identity(), usum = ge_identity();
     for (int j = (int)p.L - 1; j >= 0; j--) {
         u32 b = base + (u32)j;
-        if (b < p.B) run = ge_add(run, ge_load(bucket_sums + 32ull * ((u64)w * p.B + b)));
+        if (b < p.B) run = ge_add(run, sum_load(bucket_sums + (u64)SUM_WORDS * ((u64)w * p.B + b)));
         usum = ge_add(usum, run);
     }
     u32 log2L = 0; while ((1u << log2L) < p.L) log2L++;
