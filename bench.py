@@ -634,14 +634,15 @@ def main():
     if rank == 0:
         total_txs = args.txs * args.gpus * args.steps
         basis_e2e = args.value_basis == "end_to_end"
+        collective = "no collective (one rank)" if args.gpus == 1 else ("RCCL" if args.backend == "nccl" else args.backend + " (through host memory)")
         out = {
             "metric": "verified tx/sec (batched)", "value": round(total_txs / elapsed, 1), "unit": "tx/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": ("%d-tx mixed batch per GPU (multisig set-ups, one- and two-asset transfers, burns, co-signed transfers), %d account groups" % (args.txs, args.txs // 16)) if mixed
                        else "%d-tx batch per GPU, %d transfer(s) each, single asset, %d sender accounts" % (args.txs, args.transfers, senders),
-                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": ("one %d-tx batch cut along account groups into %d shards, RCCL MIN all-reduce of the 8-byte verdict key" % (args.txs * args.gpus, args.gpus)) if split
-                       else "tx-sharded x%d (one batch per rank), RCCL MIN all-reduce of accept bits" % args.gpus,
+                       "txs_per_gpu": args.txs, "transfers_per_tx": args.transfers, "parallelism": ("one %d-tx batch cut along account groups into %d shards, %s MIN all-reduce of the 8-byte verdict key" % (args.txs * args.gpus, args.gpus, collective)) if split
+                       else "tx-sharded x%d (one batch per rank), %s MIN all-reduce of accept bits" % (args.gpus, collective),
                        "step": ("one xhe_verify_batch call from host buffers: parse + ledger keys + host-to-device copy + verification + ledger read-back (the reference's "
                                 "Transaction::verify_batch seam); `resident` is the verification of an already uploaded batch" if basis_e2e
                                 else "one xhe_batch_verify on a batch uploaded before the timed region; `end_to_end` is the call from host buffers"),
