@@ -82,8 +82,8 @@ def test_out_of_range_and_invalid_points(engine, table, oracle):
 
 @pytest.mark.timeout(600)
 def test_many_instances_and_wide_range(engine):
-    """4096 balances below 2^40 with a table of 2^22 baby steps: every amount comes back (known from encryption); a second,
-    smaller call on the same table; one instance alone (its range spread over the lanes)."""
+    """4096 balances below 2^40 with a table of 2^22 baby steps: every amount comes back (known from encryption); smaller
+    calls on the same table (shorter items, candidate list); one instance alone (its range spread over the lanes)."""
     rnd = random.Random(11)
     t = EcdlpTable(engine, 22)
     try:
@@ -95,6 +95,9 @@ def test_many_instances_and_wide_range(engine):
         st = t.last_stats()
         assert st["instances"] == 4096 and 0 < st["steps"] <= 4096 << (40 - 22 - 1)
         assert t.decrypt_decode(kp.secret, cts[:64 * 100], 40) == amounts[:100]
+        # 256 instances: items of 64 steps, several per lane, candidates through the list
+        assert t.decrypt_decode(kp.secret, cts[:64 * 256], 40) == amounts[:256]
+        assert t.last_stats()["steps"] == 256 << (40 - 22 - 1)
         assert t.decrypt_decode(kp.secret, cts[64:128], 40) == amounts[1:2]
         assert t.decrypt_decode(kp.secret, cts[:64 * 3], 39) == [0, None, None]
     finally:
