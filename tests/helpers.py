@@ -29,7 +29,7 @@ def load_oracle():
 def load_host_primitives():
     d = os.path.join(ROOT, "tests", "support")
     cmd = ("g++ -O2 -std=c++17 -fPIC -shared -pthread -Wno-unknown-pragmas -o libxhe_host_primitives.so "
-           "xhe_host_primitives.cpp")
+           "xhe_host_primitives.cpp ../../xelis-he_amd/csrc/xhe_settings.cpp")
     lib = _ensure(os.path.join(d, "libxhe_host_primitives.so"), cmd, d)
     lib.xt_merlin_script.restype = ctypes.c_uint64
     return lib
