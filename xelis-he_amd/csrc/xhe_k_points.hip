@@ -83,7 +83,10 @@ __global__ void __launch_bounds__(64) k_bp_generators(u32 party0, u32 n_parties,
 
 
 // ---- decode ----------------------------------------------------------------------------------------
-static constexpr u32 DECODE_MAX_BLOCKS = 512;
+// Workgroups of a decode pass at most (grid-stride beyond).  Measured, resident step: 100 000 x 8 transfers 22.2 ms at 256,
+// 19.4 ms at 512, 19.0 ms at 2048; 125 000 x 1 transfer 11.4 / 10.3 / 9.8 ms; the mixed batch 11.4 / 10.8 / 11.0 ms; the parts of
+// a batch verified in parts (two in flight, each with its own decode passes) are not faster with more than 512.
+static constexpr u32 DECODE_MAX_BLOCKS = 2048, DECODE_MAX_BLOCKS_SHARED = 512;
 // A pass over the n listed entries of decs[] (the points the ledger scan waits for, the public keys, or all the others).
 // OCC = wavefronts per SIMD the kernel is compiled for: 2 (256 registers) or 4 (128 registers, a little spilling outside the
 // inverse square root's squaring chain): alone the two run within 2 % of each other, but two 256-register wavefronts fill a
@@ -181,10 +184,10 @@ void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pt
 void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab) {
     if (n_bases) hipLaunchKernelGGL(k_build_fixed_table, dim3(grid_for((u64)n_bases * n_windows * 256, 256)), dim3(256), 0, st, base_niels, n_bases, n_windows, tab);
 }
-void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background) {
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background, bool wide) {
     // a bounded grid (grid-stride loop): the decode is the widest kernel of a verification and runs beside the critical path,
     // whose few long-running wavefronts must find free slots the moment they are launched
-    const u32 max_blocks = setting("XHE_DECODE_MAX_BLOCKS") ? (u32)strtoul(setting("XHE_DECODE_MAX_BLOCKS"), nullptr, 10) : DECODE_MAX_BLOCKS;
+    const u32 max_blocks = setting("XHE_DECODE_MAX_BLOCKS") ? (u32)strtoul(setting("XHE_DECODE_MAX_BLOCKS"), nullptr, 10) : (wide ? DECODE_MAX_BLOCKS : DECODE_MAX_BLOCKS_SHARED);
     const bool occ2 = setting("XHE_DECODE_OCC") && setting("XHE_DECODE_OCC")[0] == '2';
     u32 blocks = grid_for(n, 256);
     if (blocks > max_blocks) blocks = max_blocks;

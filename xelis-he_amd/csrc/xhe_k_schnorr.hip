@@ -27,8 +27,12 @@ static constexpr u32 SIG_RATE_WORDS = 9;      // SHA3-512: 72-byte rate
 // (grid-stride beyond that) and within 128 vector registers, the size of the bulk decode's wavefronts, so that a signature
 // wavefront takes the place of exactly one of the four decode wavefronts of its SIMD.  Measured on the 100 000 x 8-transfer
 // batch: 165 registers / 1024 wavefronts 24.8 ms per step, 165 / 256 22.9 ms, 128 / 1024 22.8 ms, 128 / 512 22.3 ms, 128 / 256
-// 22.6 ms (with fewer the signatures end after everything else).  XHE_SIG_MAX_WAVES overrides the bound.
-static constexpr u32 SIG_MAX_WAVES_DEFAULT = 512;
+// 22.6 ms (with fewer the signatures end after everything else).  With the other kernels as they are now that batch no longer
+// cares (19.0-19.7 ms from 384 to 4096 wavefronts), but batches in which the signatures are a larger share of the work do: at
+// 512 they ended long after everything else - 100 000 mixed transactions (no key tables: 1.7 of 5.3 G instructions) 17.2 ms
+// against 10.9 ms at 2048, 125 000 one-transfer transactions 12.2 against 10.3 ms, 32 768 of those 3.42 against 3.04 ms.
+// XHE_SIG_MAX_WAVES overrides the bound.
+static constexpr u32 SIG_MAX_WAVES_DEFAULT = 2048;
 static u32 sig_max_waves() {
     const u32 v = [] { const char *e = setting("XHE_SIG_MAX_WAVES"); u32 x = e ? (u32)strtoul(e, nullptr, 10) : 0; return x >= 64 && x <= 65536 ? x : SIG_MAX_WAVES_DEFAULT; }();
     return v;

@@ -62,7 +62,9 @@ void launch_base_points(hipStream_t st, u32 *out);
 void launch_bp_generators(hipStream_t st, u32 n_parties, u32 cap, u32 *static_pts);
 void launch_build_fixed_table(hipStream_t st, const u32 *base_niels, u32 n_bases, u32 n_windows, u32 *tab);
 // list: the entries to decode, or null for the bulk pass (everything but the ledger scan's inputs and, unless bulk_takes_keys, the public keys)
-void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background = false);
+// wide = false: the grid stays at 512 workgroups (a part of a batch verified in parts, whose kernels share the chip with the part
+// beside it); true: up to 2048
+void launch_decode_list(hipStream_t st, const u8 *bytes, const dev_dec *decs, const u32 *list, u32 n, u32 pt_base, u32 *pts, u8 *ok, bool background = false, bool wide = true);
 void launch_point_errors(hipStream_t st, const dev_tx *txs, const dev_cm *cms, const dev_xfer *xfers, u32 n_txs, const u8 *ok, u32 *tx_err, u32 *rp_err);
 // first_rp[1] receives *noncanonical_first (the upload's range check of the scalars, k_expand_descriptors)
 void launch_verdict(hipStream_t st, const u32 *tx_err, const u32 *rp_err, u32 n_txs, unsigned long long *first_err, u32 *first_rp, const u32 *noncanonical_first);

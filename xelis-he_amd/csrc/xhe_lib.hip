@@ -1329,17 +1329,17 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
         // the transfers' ciphertexts on side stream 1; the ledger's slots (the tail of the list) on the ledger stream, behind the
         // hand-over from the part in front: nothing else of this part waits for that part's ledger
         HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
-        launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.early_end, hb.n_static, pts, ok);
+        launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.early_end, hb.n_static, pts, ok, false, !lanes);
         HIPCHK(ctx, hipEventRecord(ctx->ev_early, s1));
         if (handover && handover->bytes) {
             if (handover->after) HIPCHK(ctx, hipStreamWaitEvent(s0, handover->after, 0));
             HIPCHK(ctx, hipMemcpyAsync(B->bytes.as<u8>() + hb.cts_base, handover->src, handover->bytes, hipMemcpyDeviceToDevice, s0));
         }
-        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>() + hb.early_end, hb.n_early - hb.early_end, hb.n_static, pts, ok);
+        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>() + hb.early_end, hb.n_early - hb.early_end, hb.n_static, pts, ok, false, !lanes);
         HIPCHK(ctx, hipStreamWaitEvent(s0, ctx->ev_early, 0));
     } else {
         HIPCHK(ctx, tm.open("decode_first", s0));
-        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok);
+        launch_decode_list(s0, bytes, B->decs.as<dev_dec>(), B->early_decs.as<u32>(), hb.n_early, hb.n_static, pts, ok, false, !lanes);
         HIPCHK(ctx, tm.close("decode_first", s0));
     }
     auto enqueue_scan = [&]() -> int32_t {
@@ -1361,10 +1361,10 @@ static int32_t batch_verify_enqueue(xhe_ctx *ctx, xhe_batch *B, const uint8_t se
     HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_setup, 0));
     if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(ssig, ctx->ev_setup, 0));
     HIPCHK(ctx, tm.open("signatures", ssig));
-    launch_decode_list(ssig, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), hb.n_key, hb.n_static, pts, ok);
+    launch_decode_list(ssig, bytes, B->decs.as<dev_dec>(), B->key_decs.as<u32>(), hb.n_key, hb.n_static, pts, ok, false, !lanes);
     if (own_sig_stream) HIPCHK(ctx, hipEventRecord(ctx->ev_keys, ssig));
     HIPCHK(ctx, tm.open("decode_rest", s1));
-    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->bulk_decs.as<u32>(), hb.n_bulk, hb.n_static, pts, ok, true);
+    launch_decode_list(s1, bytes, B->decs.as<dev_dec>(), B->bulk_decs.as<u32>(), hb.n_bulk, hb.n_static, pts, ok, true, !lanes);
     HIPCHK(ctx, tm.close("decode_rest", s1));
     if (own_sig_stream) HIPCHK(ctx, hipStreamWaitEvent(s1, ctx->ev_keys, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_side_done[2], s1));             // every point that is not the ledger scan's
