@@ -469,6 +469,9 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
     std::vector<expand_ms> &ms_entries = hb.ex_mss; ms_entries.clear();       // co-signatures to verify, in transaction order
     std::unordered_map<transcript_shape, u32, transcript_shape_hash> tmpl_map;
     transcript_shape last_shape{255, 0, 0, 0, 0, 0}; u32 last_tmpl = TT_NONE;
+    // a batch of mixed transactions changes its shape with nearly every transaction and knows a handful of shapes: the ones
+    // seen last are found in a small direct-mapped table before the map is asked
+    struct recent_shape { transcript_shape shape{255, 0, 0, 0, 0, 0}; u32 tmpl = TT_NONE; } recent[16];
     hb.lg_groups.assign(16, {});
     {
         u32 sigs = 0;
@@ -482,8 +485,13 @@ static inline bool ingest_batch(host_batch &hb, const u8 *records, const u64 *of
                 transcript_shape sh{t.type, A, T, t.n_items, t.m(), lg};
                 if (!(sh == last_shape)) {
                     last_shape = sh;
-                    if (!transcript_shape_supported(sh)) last_tmpl = TT_NONE;
-                    else { auto it = tmpl_map.find(sh); last_tmpl = it != tmpl_map.end() ? it->second : (tmpl_map[sh] = build_transcript_template(hb.tmpl, sh)); }
+                    recent_shape &slot = recent[(sh.type * 5u + sh.n_commitments * 3u + sh.n_transfers + sh.n_items * 7u) & 15u];
+                    if (slot.shape == sh) last_tmpl = slot.tmpl;
+                    else {
+                        if (!transcript_shape_supported(sh)) last_tmpl = TT_NONE;
+                        else { auto it = tmpl_map.find(sh); last_tmpl = it != tmpl_map.end() ? it->second : (tmpl_map[sh] = build_transcript_template(hb.tmpl, sh)); }
+                        slot.shape = sh; slot.tmpl = last_tmpl;
+                    }
                 }
                 tmpl_of_tx[i] = last_tmpl;
                 if (last_tmpl == TT_NONE) hb.serial_txs.push_back((u32)i);
