@@ -62,7 +62,7 @@ def test_decode_equals_the_cpu_baby_step_giant_step(engine, table, oracle):
 
 @pytest.mark.timeout(600)
 def test_out_of_range_and_invalid_points(engine, table, oracle):
-    kp, pts, _ = _points(oracle, [5, (1 << 20) + 3, (1 << 30) + 1])
+    kp, pts, cts = _points(oracle, [5, (1 << 20) + 3, (1 << 30) + 1])
     oracle.xo_ecdlp_decode.restype = ctypes.c_int64
     # 2^20 + 3 and 2^30 + 1 are not below 2^20: none, as on the CPU
     assert [oracle.xo_ecdlp_decode(p, ctypes.c_uint32(20)) for p in pts] == [5, -1, -1]
@@ -71,6 +71,8 @@ def test_out_of_range_and_invalid_points(engine, table, oracle):
     # a point that is no multiple of G within the range (a public key), an invalid encoding, the identity (amount 0)
     bad = bytes([0xff]) * 32
     assert table.decode(kp.pubkey + bad + bytes(32), 24) == [None, None, 0]
+    # ciphertexts whose commitment or handle is no valid encoding: none, the valid one beside them is decoded
+    assert table.decrypt_decode(kp.secret, cts[0][:32] + bad + cts[0] + bad + cts[0][32:], 24) == [None, 5, None]
     # max_bits below the table's own reach
     assert table.decode(pts[0] + pts[1], 3) == [5, None]
     assert table.decode(b"", 24) == []
