@@ -134,7 +134,7 @@ typedef struct xhe_verdict {
  * (the reference leaves its state half-updated), and an unknown account or asset is XHE_ERR_STATE (the
  * reference's mock ledger panics).  rng_seed seeds the batch-factor generator (the reference draws
  * them from the OS RNG, src/proofs.rs:181,326); the verdict does not depend on it.
- * A batch of 64 MiB of records or 26 000 transactions and more is cut into consecutive parts inside the call (the host's parsing of part k + 1 runs
+ * A batch of 64 MiB of records or 32 000 transactions and more is cut into consecutive parts inside the call (the host's parsing of part k + 1 runs
  * beside the device's verification of part k, every part against the ledger the part before it left); verdict, index and
  * ledger are those of the batch in one piece.  XHE_SPLIT_PARTS in the environment sets the number of parts (1: never cut). */
 int32_t xhe_verify_batch(xhe_ctx *ctx, const uint8_t *records, const uint64_t *offsets, uint64_t n_txs,

@@ -39,9 +39,10 @@ static constexpr size_t STAGE_MAX = 1ull << 30;      // pinned staging memory pe
 // 4 parts 31 ms, 6 parts 25.5-26 ms, 8 parts 28 ms; 100 000 mixed transactions (100 MB) in 3 parts 27.0 ms, 5-6 parts 24.0 ms;
 // 125 000 one-transfer transactions (170 MB) in 4 parts 17.2 ms, 5-6 parts 16.2 ms; 40 000 of those in one piece 7.7 ms, 3 parts
 // 6.6 ms; 20 000 transactions of 8 transfers (78 MB) in one piece 8.0 ms, 2-3 parts 7.5 ms; 20 000 and fewer one-transfer
-// transactions are fastest in one piece.
+// transactions are fastest in one piece; 32 768 of them in one piece 6.0 ms, 2 parts 5.6 ms, 4 parts 6.6 ms; 65 536 in 2 parts
+// 9.9 ms, 4 parts 9.1 ms, 5 parts 9.7 ms, 6 parts 10.3 ms.
 static constexpr u64 SPLIT_PART_BYTES = 32ull << 20;
-static constexpr u64 SPLIT_PART_TXS = 13000;
+static constexpr u64 SPLIT_PART_TXS = 16000;
 static constexpr u64 SPLIT_PARTS_MAX = 6;
 static constexpr u32 VERDICT_SLOTS = 4;              // verifications whose verdict words may be on their way to the host at once
 // From this batch size on the signatures get a stream of their own and start beside the transcripts (measured on the
